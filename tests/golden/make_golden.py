@@ -1,0 +1,194 @@
+"""Generate the golden fixtures in this directory by RUNNING THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference, which does not exist on the GPU
+box).  It imports the reference's own `models.maskdit`, `train_utils.loss`,
+`train_utils.helper`, `sample.edm_sampler`, `utils.StackedRandomGenerator` (with the
+`_refshim` stand-ins for the uninstalled `timm` / `lmdb`), feeds them parameters drawn by
+`oracle.maskdit_oracle.init_params` (so a fixture only has to store a seed, not weights)
+and records inputs, random draws and outputs.  The reference ships no golden vectors of
+its own: these files are the pin for the oracle.
+
+    python tests/golden/make_golden.py            # rewrites tests/golden/*.npz
+
+Fixture tensors are small; parameter-sized results (gradients, updated weights) are stored
+as per-tensor checksums (sum, |sum|, L2) plus 64 sampled entries per tensor.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get('MASKDIT_REFERENCE', '/root/reference')
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(HERE, '_refshim'))
+sys.path.insert(0, REF)
+
+from oracle import maskdit_oracle as O  # noqa: E402
+
+import models.maskdit as ref_m  # noqa: E402  (reference)
+from train_utils.loss import Losses  # noqa: E402  (reference)
+from train_utils.helper import update_ema  # noqa: E402  (reference)
+from sample import edm_sampler as ref_edm_sampler  # noqa: E402  (reference)
+from utils import StackedRandomGenerator, sample as ref_sample  # noqa: E402  (reference)
+
+torch.set_num_threads(8)
+
+
+class Wrap(torch.nn.Module):
+    """Stands in for DistributedDataParallel: train_utils/loss.py:47,52 dereference
+    `net.module`, :56-58 `unwrap_model(net).model`."""
+
+    def __init__(self, m):
+        super().__init__()
+        self.module = m
+
+    @property
+    def model(self):
+        return self.module.model
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+
+def build_ref(model_type, R, P):
+    net = ref_m.Precond_models['edm'](img_resolution=R, img_channels=4, num_classes=1000,
+                                      model_type=model_type, use_decoder=True, mae_loss_coef=0.1,
+                                      pad_cls_token=False)
+    missing = net.load_state_dict(P, strict=True)
+    return net
+
+
+from tests.golden.make_golden_idx import sample_idx  # noqa: E402
+
+
+def checks(t):
+    t64 = t.detach().double().flatten()
+    idx = sample_idx(t64.numel())
+    return np.array([t64.sum().item(), t64.abs().sum().item(), t64.norm().item()]), t64[idx].numpy()
+
+
+def one_hot(idx, n=1000):
+    y = torch.zeros(len(idx), n)
+    y[torch.arange(len(idx)), idx] = 1
+    return y
+
+
+def gen_mask():
+    out = {}
+    for tag, (B, T, ratio, seed) in {'t256': (16, 256, 0.5, 7), 't1024': (4, 1024, 0.5, 8),
+                                     't256_r75': (4, 256, 0.75, 9)}.items():
+        torch.manual_seed(seed)
+        md = ref_m.get_mask(B, T, ratio, 'cpu')
+        torch.manual_seed(seed)
+        noise = torch.rand(B, T)
+        out[f'{tag}_noise'] = noise.numpy()
+        out[f'{tag}_ratio'] = np.float64(ratio)
+        out[f'{tag}_ids_keep'] = md['ids_keep'].numpy()
+        out[f'{tag}_ids_restore'] = md['ids_restore'].numpy()
+        out[f'{tag}_mask'] = md['mask'].numpy()
+    np.savez_compressed(os.path.join(HERE, 'mask.npz'), **out)
+    print('mask.npz written')
+
+
+def gen_train(tag, model_type, R, B, seed, with_grads):
+    cfg = O.make_cfg(model_type, img_resolution=R)
+    P = O.init_params(cfg, seed=seed, dezero=True)
+    net = build_ref(model_type, R, P)
+    net.train()
+    wrapped = Wrap(net)
+    g = torch.Generator().manual_seed(seed + 100)
+    images = 0.5 * torch.randn(B, 4, R, R, generator=g)
+    cls = torch.randint(0, 1000, (B,), generator=g)
+    keep = (torch.rand(B, 1, generator=g) >= 0.1).float()  # class dropout, train.py:208-209
+    labels = one_hot(cls) * keep
+    T = (R // 2) ** 2
+    # replicate the reference's internal draws in order (loss.py:35,39; maskdit.py:102)
+    torch.manual_seed(seed + 200)
+    rnd_normal = torch.randn(B, 1, 1, 1)
+    noise = torch.randn(B, 4, R, R)
+    mask_noise = torch.rand(B, T)
+    torch.manual_seed(seed + 200)
+    loss_fn = Losses['edm']()
+    loss = loss_fn(net=wrapped, images=images, labels=labels, mask_ratio=0.5, mae_loss_coef=0.1)
+    out = dict(seed=np.int64(seed), B=np.int64(B), R=np.int64(R), images=images.numpy(), cls=cls.numpy(),
+               keep=keep.numpy(), rnd_normal=rnd_normal.numpy(), noise=noise.numpy(),
+               mask_noise=mask_noise.numpy(), loss=loss.detach().numpy())
+    # D_yn (net output) for the same draws
+    md = ref_m.get_mask  # noqa
+    with torch.no_grad():
+        mdict = {k: torch.from_numpy(v) for k, v in O.get_mask_from_noise(mask_noise.numpy(), 0.5).items()}
+        sigma = (rnd_normal * 1.2 - 1.2).exp()
+        D = net(images + noise * sigma, sigma, labels, mask_ratio=0.5, mask_dict=mdict)['x']
+    out['D_yn'] = D.numpy()
+    names = [k for k in P if k not in O.NON_TRAINABLE]
+    out['param_names'] = np.array(names)
+    pc = [checks(P[k]) for k in names]
+    out['param_sums'] = np.stack([c[0] for c in pc])
+    if with_grads:
+        loss.mean().backward()
+        sd = dict(net.named_parameters())
+        gc = [checks(sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])) for k in names]
+        out['grad_sums'] = np.stack([c[0] for c in gc])
+        out['grad_samples'] = np.stack([c[1] for c in gc])
+        # one optimizer step + EMA (train.py:141,223-230): torch AdamW == apex FusedAdam(adam_w_mode, wd 0)
+        import copy
+        ema = copy.deepcopy(net)
+        opt = torch.optim.AdamW([p for p in net.parameters() if p.requires_grad], lr=1e-4, betas=(0.9, 0.999),
+                                eps=1e-8, weight_decay=0)
+        opt.step()
+        update_ema(ema, net, decay=0.9999)
+        sd = dict(net.named_parameters())
+        se = dict(ema.named_parameters())
+        uc = [checks(sd[k]) for k in names]
+        ec = [checks(se[k]) for k in names]
+        out['upd_sums'] = np.stack([c[0] for c in uc])
+        out['upd_samples'] = np.stack([c[1] for c in uc])
+        out['ema_sums'] = np.stack([c[0] for c in ec])
+        out['ema_samples'] = np.stack([c[1] for c in ec])
+    np.savez_compressed(os.path.join(HERE, f'{tag}.npz'), **out)
+    print(f'{tag}.npz written; loss[:4] =', loss.detach().numpy()[:4])
+
+
+def gen_sampler(tag, model_type, R, seeds, num_steps, cfg_scale, seed):
+    cfg = O.make_cfg(model_type, img_resolution=R)
+    P = O.init_params(cfg, seed=seed, dezero=True)
+    net = build_ref(model_type, R, P)
+    net.eval()
+    rnd = StackedRandomGenerator('cpu', seeds)
+    latents = rnd.randn([len(seeds), 4, R, R])
+    cls = rnd.randint(1000, size=[len(seeds)])
+    labels = torch.eye(1000)[cls]
+    with torch.no_grad():
+        z = ref_edm_sampler(net, latents.float(), labels.float(), randn_like=rnd.randn_like,
+                            cfg_scale=cfg_scale, num_steps=num_steps)
+        z_nocfg = ref_edm_sampler(net, latents.float(), labels.float(), randn_like=rnd.randn_like,
+                                  cfg_scale=None, num_steps=num_steps)
+    np.savez_compressed(os.path.join(HERE, f'{tag}.npz'), seed=np.int64(seed), seeds=np.array(seeds),
+                        latents=latents.numpy(), cls=cls.numpy(), num_steps=np.int64(num_steps),
+                        cfg_scale=np.float64(cfg_scale), z=z.numpy(), z_nocfg=z_nocfg.numpy())
+    print(f'{tag}.npz written; z std', z.std().item())
+
+
+def gen_moments():
+    g = torch.Generator().manual_seed(5)
+    mom = torch.cat([2.745 * torch.randn(4, 4, 32, 32, generator=g), torch.full((4, 4, 32, 32), -10.0)], 1)
+    mom[0, 4:] = 25.0  # exercises the clamp (utils.py:61)
+    torch.manual_seed(11)
+    rn = torch.randn(4, 4, 32, 32)
+    torch.manual_seed(11)
+    z = ref_sample(mom)
+    np.savez_compressed(os.path.join(HERE, 'moments.npz'), moments=mom.numpy(), randn=rn.numpy(), z=z.numpy())
+    print('moments.npz written')
+
+
+if __name__ == '__main__':
+    gen_mask()
+    gen_moments()
+    gen_train('s2_train', 'DiT-S/2', 32, 16, seed=0, with_grads=True)       # BASELINE config 1
+    gen_train('s2_512_fwd', 'DiT-S/2', 64, 2, seed=3, with_grads=False)     # T=1024 / L=512 shapes
+    gen_train('xl2_fwd', 'DiT-XL/2', 32, 2, seed=4, with_grads=False)       # hd=72 path
+    gen_sampler('s2_sampler', 'DiT-S/2', 32, [100, 101, 102, 103], 6, 1.5, seed=2)
