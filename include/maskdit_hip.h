@@ -1,0 +1,220 @@
+/*
+ * maskdit_hip.h -- C ABI of libmaskdit_hip.so, the gfx950 (MI355X) kernel library behind
+ * the MaskDiT training / sampling hot path.
+ *
+ * The reference (Anima-Lab/MaskDiT) has no FFI: its boundary is the Python object surface
+ * (SURVEY.md section 8b).  Each entry point below therefore cites the reference Python code
+ * whose arithmetic it replaces (paths relative to the reference repo).  All pointers are
+ * DEVICE pointers unless stated; every call is asynchronous on `stream`, performs no
+ * allocation and no host synchronisation (hipGraph-capturable), and returns 0 on success or
+ * a negative code (mdt_last_error() gives the message).  bf16 = IEEE bfloat16 stored as
+ * uint16_t; "f32" = float.
+ */
+#ifndef MASKDIT_HIP_H
+#define MASKDIT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* mdt_stream_t; /* hipStream_t */
+typedef uint16_t mdt_bf16;
+
+const char* mdt_last_error(void);
+int mdt_version(void);
+
+/* ---------------------------------------------------------------- GEMMs (MFMA bf16) ---- */
+
+enum mdt_epilogue {
+  MDT_EPI_BF16 = 0,     /* out = bf16(acc + bias)                                              */
+  MDT_EPI_F32 = 1,      /* outf = acc + bias   (and out = bf16 of it when out != NULL)         */
+  MDT_EPI_GELU = 2,     /* out = h = bf16(acc+bias); out2 = bf16(gelu_tanh(h))                 */
+  MDT_EPI_SILU = 3,     /* out = h; out2 = bf16(silu(h))                                       */
+  MDT_EPI_GATE_RES = 4, /* out = y = bf16(acc+bias); outf = res + gate[row/rows_per_sample]*y  */
+  MDT_EPI_DGELU = 5,    /* out = bf16(acc * gelu_tanh'(aux))                                   */
+  MDT_EPI_DSILU = 6     /* out = bf16(acc * silu'(aux))                                        */
+};
+
+/* C[M,N] = A[M,K] * B[N,K]^T (+bias) with a fused epilogue.  Replaces every nn.Linear on the
+ * path: timm Attention.qkv/.proj, timm Mlp.fc1/.fc2 (models/maskdit.py:178,182), adaLN
+ * Linear (:183-186), t_embedder (:34-38), y_embedder (:75), decoder_layer.linear (:203); the
+ * GELU(tanh) (:181) and `x + gate * f(x)` (:190-191) are the fused epilogues.  Backward
+ * data-gradients use the same kernel with the transposed weight shadow as B.
+ * Requires N % 128 == 0, K % 64 == 0, 16-byte aligned rows; M arbitrary. */
+typedef struct {
+  const mdt_bf16* A; int lda;
+  const mdt_bf16* B; int ldb;
+  int M, N, K;
+  const float* bias;
+  int epi;
+  mdt_bf16* out; int ldo;
+  mdt_bf16* out2; int ldo2;
+  float* outf; int ldof;
+  const float* res; int ldres;
+  const float* gate; int gate_ld; int rows_per_sample;
+  const mdt_bf16* aux; int ldaux;
+} mdt_gemm_nt_args;
+int mdt_gemm_nt(const mdt_gemm_nt_args* a, mdt_stream_t stream);
+
+/* C[N1,N2] += A[M,N1]^T * B[M,N2]  (f32 atomic accumulate, split over M).  Replaces the
+ * autograd weight-gradient of every nn.Linear above (reference: torch autograd under
+ * accelerator.backward, train.py:220).  Requires M % 64 == 0, row pitches padded to
+ * multiples of 128 columns; only [n1_valid, n2_valid] is stored. */
+typedef struct {
+  const mdt_bf16* A; int lda;
+  const mdt_bf16* B; int ldb;
+  int M, N1, N2;
+  float* C; int ldc;
+  int n1_valid, n2_valid;
+  int splits; /* 0 = auto */
+} mdt_gemm_tn_args;
+int mdt_gemm_tn(const mdt_gemm_tn_args* a, mdt_stream_t stream);
+
+/* ---------------------------------------------------------------- attention ------------ */
+
+/* softmax(q k^T / sqrt(hd)) v for packed qkv [B*L, 3*H*hd] (timm Attention, call site
+ * models/maskdit.py:178).  out [B*L, H*hd] bf16, lse [B*H*L] f32 (log2 domain).
+ * hd in {32, 64, 72, 80}; L % 64 == 0. */
+int mdt_attn_fwd(const mdt_bf16* qkv, mdt_bf16* out, float* lse, int B, int L, int H, int hd,
+                 mdt_stream_t stream);
+/* backward of the above: dqkv [B*L, 3*H*hd] from dout; delta is [B*H*L] f32 scratch. */
+int mdt_attn_bwd(const mdt_bf16* qkv, const mdt_bf16* out, const mdt_bf16* dout, const float* lse,
+                 float* delta, mdt_bf16* dqkv, int B, int L, int H, int hd, mdt_stream_t stream);
+
+/* ---------------------------------------------------------------- norm / modulate ------ */
+
+/* xn = LayerNorm(x) * (1 + scale[b]) + shift[b]  (models/maskdit.py:19-20,177,190-191).
+ * x f32 [M,D]; shift/scale f32 with row pitch mod_ld, sample = row / rows_per_sample;
+ * xn bf16 [M,D]; stats[2*M] = (mean, rstd). */
+int mdt_ln_modulate_fwd(const float* x, const float* shift, const float* scale, int mod_ld,
+                        int rows_per_sample, mdt_bf16* xn, float* stats, int M, int D,
+                        mdt_stream_t stream);
+/* backward: dx (+)= dLN(dxn * (1+scale)); dshift[b] += sum_l dxn; dscale[b] += sum_l dxn*xhat. */
+int mdt_ln_modulate_bwd(const mdt_bf16* dxn, const float* x, const float* stats, const float* scale,
+                        int mod_ld, int rows_per_sample, float* dx, int accumulate, float* dshift,
+                        float* dscale, int dmod_ld, int M, int D, mdt_stream_t stream);
+/* backward of `x + gate * y` (models/maskdit.py:190-191): dys = bf16(gate[b] * dx),
+ * dgate[b] += sum_l dx * y, dbias += sum_rows dys. */
+int mdt_gate_bwd(const float* dx, const mdt_bf16* y, const float* gate, int mod_ld,
+                 int rows_per_sample, mdt_bf16* dys, float* dgate, int dmod_ld, float* dbias, int M,
+                 int D, mdt_stream_t stream);
+/* out[n] += sum_m in[m,n]  (bias gradients). */
+int mdt_colsum_bf16(const mdt_bf16* in, int ld, float* out, int M, int N, mdt_stream_t stream);
+
+/* ---------------------------------------------------------------- masking -------------- */
+
+/* get_mask (models/maskdit.py:88-113) from a noise tensor [B,T]: stable ascending argsort.
+ * ids_* are int64 (reference dtype); ids32 = [B, 2T] int32 (shuffle | restore) for kernels. */
+int mdt_mask_sort(const float* noise, int B, int T, int len_keep, int64_t* ids_shuffle,
+                  int64_t* ids_restore, float* mask, int32_t* ids32, mdt_stream_t stream);
+
+/* ---------------------------------------------------------------- embed / unmask / final  */
+
+/* PatchEmbed (Conv2d k=s=p as a per-patch linear) + pos_embed + mask_out_token gather
+ * (models/maskdit.py:116-127,278,475-483).  x [B,C,R,R] f32, scale[b] (c_in) optional,
+ * W [D, C*p*p] f32, ids32 shuffle (NULL = all T tokens) -> out f32 [B, L, D]. */
+int mdt_patch_embed_fwd(const float* x, const float* in_scale, const float* W, const float* bias,
+                        const float* pos, const int32_t* ids, int ids_ld, float* out, int B, int C,
+                        int R, int p, int L, int D, mdt_stream_t stream);
+int mdt_patch_embed_bwd(const float* x, const float* in_scale, const float* dout, const int32_t* ids,
+                        int ids_ld, float* dW, float* dbias, int B, int C, int R, int p, int L, int D,
+                        mdt_stream_t stream);
+
+/* timestep_embedding (models/maskdit.py:41-60): out bf16 [B,256] = [cos(t f), sin(t f)]. */
+int mdt_timestep_embed(const float* t, mdt_bf16* out, int ld, int B, int dim, mdt_stream_t stream);
+/* elementwise helpers on [rows, cols] */
+int mdt_cast_f32_bf16(const float* in, int ldi, mdt_bf16* out, int ldo, int rows, int cols, int act,
+                      mdt_stream_t stream); /* act: 0 none, 1 silu */
+int mdt_add_f32(const float* a, const float* b, float* out, long n, mdt_stream_t stream);
+int mdt_silu_bwd(const float* dy, const float* x, mdt_bf16* dx, long n, mdt_stream_t stream);
+
+/* unmask_tokens + decoder_pos_embed (models/maskdit.py:157-163,543-545).
+ * xdec bf16 [B,L,Dd]; restore int32 [B,T] (NULL = identity, L == T); out f32 [B,T,Dd]. */
+int mdt_unmask_fwd(const mdt_bf16* xdec, const int32_t* restore, int ids_ld, const float* mask_token,
+                   const float* pos, float* out, int B, int T, int L, int Dd, mdt_stream_t stream);
+int mdt_unmask_bwd(const float* dout, const int32_t* shuffle, int ids_ld, mdt_bf16* dxdec,
+                   float* dmask_token, int B, int T, int L, int Dd, mdt_stream_t stream);
+
+/* FinalLayer + unpatchify (models/maskdit.py:216-234,411-424): x f32 [B*T, Dd] ->
+ * LN-modulate -> Linear(Dd -> p*p*C) -> F [B,C,R,R] f32. */
+int mdt_final_fwd(const float* x, const float* shift, const float* scale, int mod_ld, const float* W,
+                  const float* bias, float* F, float* stats, int B, int T, int Dd, int C, int p,
+                  mdt_stream_t stream);
+int mdt_final_bwd(const float* dF, const float* x, const float* stats, const float* shift,
+                  const float* scale, int mod_ld, const float* W, float* dx, float* dW, float* dbias,
+                  float* dshift, float* dscale, int dmod_ld, int B, int T, int Dd, int C, int p,
+                  mdt_stream_t stream);
+
+/* ---------------------------------------------------------------- EDM precond / loss ---- */
+
+/* EDMLoss noise draw + EDMPrecond coefficients (train_utils/loss.py:35-39,
+ * models/maskdit.py:764-767): sigma = exp(rnd*P_std+P_mean); coef[i*B + b], i over (c_skip,
+ * c_out, c_in, c_noise, weight, sigma, -, -) (8 x B floats); yn = y + noise*sigma; xin = c_in*yn. */
+int mdt_edm_prep(const float* y, const float* rnd_normal, const float* noise, float* coef, float* yn,
+                 float* xin, int B, int chw, float P_mean, float P_std, float sigma_data,
+                 mdt_stream_t stream);
+/* D = c_skip*yn + c_out*F; per-sample loss (train_utils/loss.py:44-52,88-101).  mask NULL =>
+ * plain mean.  */
+int mdt_edm_loss_fwd(const float* F, const float* yn, const float* y, const float* coef,
+                     const float* mask, float mae_coef, float* D, float* loss, int B, int C, int R,
+                     int p, mdt_stream_t stream);
+int mdt_edm_loss_bwd(const float* dloss, const float* D, const float* yn, const float* y,
+                     const float* coef, const float* mask, float mae_coef, float* dF, int B, int C,
+                     int R, int p, mdt_stream_t stream);
+/* Precond only (sampling / generic path): coef from sigma[b]; D = c_skip*x + c_out*F. */
+int mdt_precond_coef(const float* sigma, float* coef, int B, float sigma_data, mdt_stream_t stream);
+int mdt_scale_rows(const float* x, const float* coef, int coef_idx, float* out, int B, int chw,
+                   mdt_stream_t stream);
+int mdt_precond_out(const float* x, const float* F, const float* coef, float* D, int B, int chw,
+                    mdt_stream_t stream);
+
+/* ---------------------------------------------------------------- optimizer ------------- */
+
+/* apex FusedAdam(adam_w_mode=True) step (train.py:141,226) fused with update_ema
+ * (train_utils/helper.py:47-58) and the bf16 weight-shadow refresh, one pass over the flat
+ * parameter arena.  grad is multiplied by grad_scale first.  ema / w16 may be NULL. */
+int mdt_adamw_ema_step(float* p, const float* g, float* m, float* v, float* ema, mdt_bf16* w16, long n,
+                       float lr, float beta1, float beta2, float eps, float weight_decay, float bc1,
+                       float bc2, float ema_decay, float grad_scale, mdt_stream_t stream);
+int mdt_ema_update(float* ema, const float* p, long n, float decay, mdt_stream_t stream);
+/* batched [rows, cols] -> [cols, rows] bf16 transposes inside one arena; table = int64
+ * (src_off, dst_off, rows, cols, tile_start) x n_entries (device), total_tiles over 64x64 tiles. */
+int mdt_transpose_bf16_batched(const mdt_bf16* src, mdt_bf16* dst, const int64_t* table, int n_entries,
+                               int total_tiles, mdt_stream_t stream);
+
+/* ---------------------------------------------------------------- sampler --------------- */
+
+/* edm_sampler (sample.py:30-66), S_churn = 0.  State fp64.  t_steps: device fp64 [N+1];
+ * step_idx: device int32 advanced by mdt_sampler_advance so one captured hipGraph replays
+ * every step.  cfg != 0 => F holds [cond; uncond] halves (models/maskdit.py:559-587). */
+int mdt_sampler_prep(const double* x, const double* t_steps, const int32_t* step_idx, int which,
+                     float* xin, float* sigma_out, int B, int chw, int dup, float sigma_data,
+                     mdt_stream_t stream);
+int mdt_sampler_euler(const double* x_hat, const float* F, const double* t_steps,
+                      const int32_t* step_idx, float cfg_scale, int use_cfg, double* x_next,
+                      double* d_cur, int B, int chw, float sigma_data, mdt_stream_t stream);
+int mdt_sampler_heun(const double* x_hat, double* x_next, const float* F, const double* d_cur,
+                     const double* t_steps, const int32_t* step_idx, float cfg_scale, int use_cfg,
+                     int B, int chw, float sigma_data, mdt_stream_t stream);
+int mdt_sampler_advance(int32_t* step_idx, mdt_stream_t stream);
+/* classifier-free guidance combine on F = [cond; uncond] (models/maskdit.py:580-583), n = B*chw */
+int mdt_cfg_combine(const float* F, float cfg_scale, float* out, long n, mdt_stream_t stream);
+
+/* hipGraph helpers (stream capture of a sequence of the calls above). */
+int mdt_graph_begin(mdt_stream_t stream);
+int mdt_graph_end(mdt_stream_t stream, void** graph_exec_out);
+int mdt_graph_launch(void* graph_exec, mdt_stream_t stream);
+int mdt_graph_destroy(void* graph_exec);
+
+/* timing helper: HIP events on an arbitrary stream (bench.py roofline leg). */
+int mdt_event_create(void** ev);
+int mdt_event_record(void* ev, mdt_stream_t stream);
+int mdt_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on stop */
+int mdt_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

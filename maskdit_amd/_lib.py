@@ -1,0 +1,137 @@
+"""ctypes binding of libmaskdit_hip.so (the C ABI declared in include/maskdit_hip.h).
+
+The library is the product: if it is missing or fails to load, everything in this package
+that computes fails loudly -- there is no eager / CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmaskdit_hip.so')
+CSRC = os.path.join(_HERE, 'csrc')
+
+vp = C.c_void_p
+i32 = C.c_int
+i64 = C.c_long
+f32 = C.c_float
+
+EPI_BF16, EPI_F32, EPI_GELU, EPI_SILU, EPI_GATE_RES, EPI_DGELU, EPI_DSILU = range(7)
+
+
+class GemmNTArgs(C.Structure):
+    _fields_ = [('A', vp), ('lda', i32), ('B', vp), ('ldb', i32), ('M', i32), ('N', i32), ('K', i32),
+                ('bias', vp), ('epi', i32), ('out', vp), ('ldo', i32), ('out2', vp), ('ldo2', i32),
+                ('outf', vp), ('ldof', i32), ('res', vp), ('ldres', i32), ('gate', vp), ('gate_ld', i32),
+                ('rows_per_sample', i32), ('aux', vp), ('ldaux', i32)]
+
+
+class GemmTNArgs(C.Structure):
+    _fields_ = [('A', vp), ('lda', i32), ('B', vp), ('ldb', i32), ('M', i32), ('N1', i32), ('N2', i32),
+                ('C', vp), ('ldc', i32), ('n1_valid', i32), ('n2_valid', i32), ('splits', i32)]
+
+
+# name -> argtypes (the trailing stream argument is added to every compute entry)
+_PROTOS = {
+    'mdt_gemm_nt': [C.POINTER(GemmNTArgs)],
+    'mdt_gemm_tn': [C.POINTER(GemmTNArgs)],
+    'mdt_attn_fwd': [vp, vp, vp, i32, i32, i32, i32],
+    'mdt_attn_bwd': [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32],
+    'mdt_ln_modulate_fwd': [vp, vp, vp, i32, i32, vp, vp, i32, i32],
+    'mdt_ln_modulate_bwd': [vp, vp, vp, vp, i32, i32, vp, i32, vp, vp, i32, i32, i32],
+    'mdt_gate_bwd': [vp, vp, vp, i32, i32, vp, vp, i32, vp, i32, i32],
+    'mdt_colsum_bf16': [vp, i32, vp, i32, i32],
+    'mdt_mask_sort': [vp, i32, i32, i32, vp, vp, vp, vp],
+    'mdt_patch_embed_fwd': [vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, i32, i32, i32, i32],
+    'mdt_patch_embed_bwd': [vp, vp, vp, vp, i32, vp, vp, i32, i32, i32, i32, i32, i32],
+    'mdt_timestep_embed': [vp, vp, i32, i32, i32],
+    'mdt_cast_f32_bf16': [vp, i32, vp, i32, i32, i32, i32],
+    'mdt_add_f32': [vp, vp, vp, i64],
+    'mdt_silu_bwd': [vp, vp, vp, i64],
+    'mdt_unmask_fwd': [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32],
+    'mdt_unmask_bwd': [vp, vp, i32, vp, vp, i32, i32, i32, i32],
+    'mdt_final_fwd': [vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32],
+    'mdt_final_bwd': [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32],
+    'mdt_edm_prep': [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, f32],
+    'mdt_edm_loss_fwd': [vp, vp, vp, vp, vp, f32, vp, vp, i32, i32, i32, i32],
+    'mdt_edm_loss_bwd': [vp, vp, vp, vp, vp, vp, f32, vp, i32, i32, i32, i32],
+    'mdt_precond_coef': [vp, vp, i32, f32],
+    'mdt_scale_rows': [vp, vp, i32, vp, i32, i32],
+    'mdt_precond_out': [vp, vp, vp, vp, i32, i32],
+    'mdt_adamw_ema_step': [vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, f32, f32, f32],
+    'mdt_ema_update': [vp, vp, i64, f32],
+    'mdt_transpose_bf16_batched': [vp, vp, vp, i32, i32],
+    'mdt_sampler_prep': [vp, vp, vp, i32, vp, vp, i32, i32, i32, f32],
+    'mdt_sampler_euler': [vp, vp, vp, vp, f32, i32, vp, vp, i32, i32, f32],
+    'mdt_sampler_heun': [vp, vp, vp, vp, vp, vp, f32, i32, i32, i32, f32],
+    'mdt_sampler_advance': [vp],
+    'mdt_cfg_combine': [vp, f32, vp, i64],
+}
+# entries without the trailing stream
+_PLAIN = {
+    'mdt_graph_begin': [vp],
+    'mdt_graph_end': [vp, C.POINTER(vp)],
+    'mdt_graph_launch': [vp, vp],
+    'mdt_graph_destroy': [vp],
+    'mdt_event_create': [C.POINTER(vp)],
+    'mdt_event_record': [vp, vp],
+    'mdt_event_elapsed_ms': [vp, vp, C.POINTER(f32)],
+    'mdt_event_destroy': [vp],
+}
+EXPORTED = sorted(list(_PROTOS) + list(_PLAIN) + ['mdt_last_error', 'mdt_version'])
+
+
+class MaskDiTLibError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into libmaskdit_hip.so (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(['make', '-C', CSRC, '-j', str(min(8, os.cpu_count() or 1))], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:])
+        print(r.stderr[-4000:])
+    if r.returncode != 0:
+        raise MaskDiTLibError('building libmaskdit_hip.so failed (see compiler output above)')
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the shared library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MaskDiTLibError(
+            f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'(or `make -C {CSRC}`).  maskdit_amd has no non-HIP fallback.')
+    L = C.CDLL(LIB_PATH)
+    for name, argt in _PROTOS.items():
+        fn = getattr(L, name)
+        fn.argtypes = argt + [vp]
+        fn.restype = i32
+    for name, argt in _PLAIN.items():
+        fn = getattr(L, name)
+        fn.argtypes = argt
+        fn.restype = i32
+    L.mdt_last_error.restype = C.c_char_p
+    L.mdt_last_error.argtypes = []
+    L.mdt_version.restype = i32
+    L.mdt_version.argtypes = []
+    _lib = L
+    return L
+
+
+def check(rc: int, what: str = ''):
+    if rc != 0:
+        raise MaskDiTLibError(f'{what} failed ({rc}): {lib().mdt_last_error().decode()}')
+
+
+def call(name: str, *args):
+    """Checked call of a compute entry; the last positional argument must be the stream."""
+    check(getattr(lib(), name)(*args), name)

@@ -1,0 +1,405 @@
+// Fused multi-head self-attention for packed qkv, forward and backward, gfx950 MFMA.
+//
+// Reference: timm Attention called from DiTBlock (models/maskdit.py:178,190):
+//   qkv = Linear(x).reshape(B,L,3,H,hd); softmax(q k^T / sqrt(hd)) v.
+//
+// Shapes on this path: L in {128,256,512,1024}, hd in {32 (decoder), 64, 72 (XL), 80}.  Attention
+// is < 2 % of the step FLOPs at 256^2, so the design goal is "never spill, never
+// bank-conflict, no extra HBM passes", not peak MFMA rate:
+//   * one workgroup = 4 waves = 64 query (or key) rows of one (sample, head); K/V (or Q/dO)
+//     blocks of 64 rows staged in LDS with odd 16-byte-chunk row pitch (conflict-free
+//     ds_read_b128), zero-padded to the MFMA contraction width (hd 72 -> 96);
+//   * scores are computed TRANSPOSED (S^T = K Q^T) so each lane owns one query column:
+//     softmax statistics are lane-local (+2 shuffles), and the bf16 probabilities are already
+//     laid out as the B operand of the second MFMA (O^T = V^T P^T) -- no LDS round trip;
+//   * V^T / K^T / Q^T / dO^T operands come from ds_read_b64_tr_b16 (hardware transpose read);
+//   * backward = two kernels (dQ; dK+dV), each recomputing P from the saved log-sum-exp,
+//     no atomics.
+#include "common.h"
+#include "../../include/maskdit_hip.h"
+
+template <int HD>
+struct AttnCfg {
+  static constexpr int HDK = (HD + 31) / 32 * 32;   // contraction width (QK^T, dP)
+  static constexpr int HDN = (HD + 15) / 16 * 16;   // output width (PV, dQ, dK, dV)
+  static constexpr int KSTEPS = HDK / 32;
+  static constexpr int NFRAG = HDN / 16;
+  static constexpr int CH = HD / 8;                 // valid 16-byte chunks per row
+  static constexpr int PITCH_CH = (HDK / 8) | 1;    // odd chunk pitch
+  static constexpr int PITCH = PITCH_CH * 16;       // bytes
+  static constexpr int TILE_BYTES = 64 * PITCH;
+};
+
+// stage 64 rows x HD (bf16) from global (row stride ld elements) into LDS with pitch PITCH;
+// columns [HD, HDK) must have been zeroed once.
+template <int HD>
+__device__ __forceinline__ void stage_tile(char* lds, const bf16* g, long ld, int tid) {
+  using C = AttnCfg<HD>;
+  for (int idx = tid; idx < 64 * C::CH; idx += 256) {
+    int r = idx / C::CH, c = idx - r * C::CH;
+    bf16x8 v = *(const bf16x8*)(g + (long)r * ld + c * 8);
+    *(bf16x8*)(lds + r * C::PITCH + c * 16) = v;
+  }
+}
+template <int HD>
+__device__ __forceinline__ void zero_pad(char* lds, int tid) {
+  using C = AttnCfg<HD>;
+  constexpr int PADCH = C::PITCH_CH - C::CH;
+  if (PADCH > 0) {
+    for (int idx = tid; idx < 64 * PADCH; idx += 256) {
+      int r = idx / PADCH, c = C::CH + (idx - r * PADCH);
+      bf16x8 z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = (bf16)0.f;
+      *(bf16x8*)(lds + r * C::PITCH + c * 16) = z;
+    }
+  }
+}
+
+// operand fragment straight from global: lane (idx = lane&15 -> row, g = lane>>4) gets
+// elements [32s + 8g, +8) of its row, zero beyond HD.
+template <int HD>
+__device__ __forceinline__ void load_frag_global(bf16x8* f, const bf16* rowptr, int g) {
+  using C = AttnCfg<HD>;
+#pragma unroll
+  for (int s = 0; s < C::KSTEPS; ++s) {
+    int d = 32 * s + 8 * g;
+    if (d < HD) {
+      f[s] = *(const bf16x8*)(rowptr + d);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[s][e] = (bf16)0.f;
+    }
+  }
+}
+
+// normal (row-major) fragment read: row `row`, contraction step s
+template <int HD>
+__device__ __forceinline__ bf16x8 frag_rows(const char* tile, int row, int s, int g) {
+  return *(const bf16x8*)(tile + row * AttnCfg<HD>::PITCH + (4 * s + g) * 16);
+}
+// transposed fragment: MFMA row index = column (16*fd + lane&15) of the tile, contraction slots
+// (g, e) <-> tile rows  rbase + 16*(e>>2) + 4g + (e&3).
+template <int HD>
+__device__ __forceinline__ bf16x8 frag_cols(const char* tile, int rbase, int fd, int i16, int g) {
+  const char* q = tile + (rbase + 4 * g + (i16 >> 2)) * AttnCfg<HD>::PITCH + (16 * fd + 4 * (i16 & 3)) * 2;
+  return cat4(lds_tr_read(q), lds_tr_read(q + 16 * AttnCfg<HD>::PITCH));
+}
+
+__device__ __forceinline__ bf16x8 pack_pair(f32x4 a, f32x4 b) {
+  bf16x8 r;
+  r[0] = f2bf(a[0]); r[1] = f2bf(a[1]); r[2] = f2bf(a[2]); r[3] = f2bf(a[3]);
+  r[4] = f2bf(b[0]); r[5] = f2bf(b[1]); r[6] = f2bf(b[2]); r[7] = f2bf(b[3]);
+  return r;
+}
+
+__device__ __forceinline__ float group_sum(float v) {  // sum over the 4 lane groups (same lane&15)
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ float group_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// forward: grid (L/64, B*H)
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                       float* __restrict__ lse, int L, int H, float scale_log2e) {
+  using C = AttnCfg<HD>;
+  __shared__ __attribute__((aligned(16))) char smem[2 * C::TILE_BYTES];
+  char* Ks = smem;
+  char* Vs = smem + C::TILE_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int D = H * HD;
+  const long ld = 3L * D;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const bf16* base = qkv + (long)b * L * ld + h * HD;
+
+  zero_pad<HD>(Ks, tid);
+  zero_pad<HD>(Vs, tid);
+
+  bf16x8 qf[C::KSTEPS];
+  load_frag_global<HD>(qf, base + (long)(q0 + i16) * ld, g);
+
+  f32x4 o[C::NFRAG];
+#pragma unroll
+  for (int f = 0; f < C::NFRAG; ++f) o[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float m_run = -1e30f, l_run = 0.f;
+
+  for (int kb = 0; kb < L; kb += 64) {
+    __syncthreads();
+    stage_tile<HD>(Ks, base + (long)kb * ld + D, ld, tid);
+    stage_tile<HD>(Vs, base + (long)kb * ld + 2 * D, ld, tid);
+    __syncthreads();
+    // S^T fragments: rows = keys 16f + 4g + r, col = query i16
+    f32x4 s[4];
+    float mx = -1e30f;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      s[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < C::KSTEPS; ++ks) s[f] = mfma16(frag_rows<HD>(Ks, 16 * f + i16, ks, g), qf[ks], s[f]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[f][r] *= scale_log2e;
+        mx = fmaxf(mx, s[f][r]);
+      }
+    }
+    mx = group_max(mx);
+    float m_new = fmaxf(m_run, mx);
+    float alpha = exp2f(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float pv = exp2f(s[f][r] - m_new);
+        s[f][r] = pv;
+        psum += pv;
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int f = 0; f < C::NFRAG; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[f][r] *= alpha;
+    // O^T += V^T P^T : contraction over keys, two steps of 32
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 pf = pack_pair(s[2 * ks], s[2 * ks + 1]);
+#pragma unroll
+      for (int f = 0; f < C::NFRAG; ++f) o[f] = mfma16(frag_cols<HD>(Vs, 32 * ks, f, i16, g), pf, o[f]);
+    }
+  }
+  float l_tot = group_sum(l_run);
+  float inv = 1.f / l_tot;
+  bf16* orow = out + ((long)b * L + q0 + i16) * D + h * HD;
+#pragma unroll
+  for (int f = 0; f < C::NFRAG; ++f) {
+    int d = 16 * f + 4 * g;
+    if (d < HD) {
+      bf16x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = f2bf(o[f][r] * inv);
+      *(bf16x4*)(orow + d) = v;
+    }
+  }
+  if (g == 0) lse[(long)bh * L + q0 + i16] = m_run + log2f(l_tot);
+}
+
+// ------------------------------------------------------------------------------------------
+// backward dQ (+ delta): grid (L/64, B*H); wave owns 16 queries, loops over key blocks.
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                          const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                          float* __restrict__ delta, bf16* __restrict__ dqkv, int L,
+                                                          int H, float scale, float scale_log2e) {
+  using C = AttnCfg<HD>;
+  __shared__ __attribute__((aligned(16))) char smem[2 * C::TILE_BYTES];
+  char* Ks = smem;
+  char* Vs = smem + C::TILE_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int D = H * HD;
+  const long ld = 3L * D;
+  const int q0 = blockIdx.x * 64 + wave * 16;
+  const bf16* base = qkv + (long)b * L * ld + h * HD;
+
+  zero_pad<HD>(Ks, tid);
+  zero_pad<HD>(Vs, tid);
+
+  bf16x8 qf[C::KSTEPS], dof[C::KSTEPS], of[C::KSTEPS];
+  const long orow = ((long)b * L + q0 + i16) * D + h * HD;
+  load_frag_global<HD>(qf, base + (long)(q0 + i16) * ld, g);
+  load_frag_global<HD>(dof, dout + orow, g);
+  load_frag_global<HD>(of, out + orow, g);
+  float dl = 0.f;
+#pragma unroll
+  for (int s = 0; s < C::KSTEPS; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dl += bf2f(dof[s][e]) * bf2f(of[s][e]);
+  dl = group_sum(dl);
+  const float my_lse = lse[(long)bh * L + q0 + i16];
+  if (g == 0) delta[(long)bh * L + q0 + i16] = dl;
+
+  f32x4 dq[C::NFRAG];
+#pragma unroll
+  for (int f = 0; f < C::NFRAG; ++f) dq[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int kb = 0; kb < L; kb += 64) {
+    __syncthreads();
+    stage_tile<HD>(Ks, base + (long)kb * ld + D, ld, tid);
+    stage_tile<HD>(Vs, base + (long)kb * ld + 2 * D, ld, tid);
+    __syncthreads();
+    f32x4 ds[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < C::KSTEPS; ++ks) {
+        s = mfma16(frag_rows<HD>(Ks, 16 * f + i16, ks, g), qf[ks], s);
+        dp = mfma16(frag_rows<HD>(Vs, 16 * f + i16, ks, g), dof[ks], dp);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float pv = exp2f(s[r] * scale_log2e - my_lse);
+        ds[f][r] = pv * (dp[r] - dl) * scale;
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 dsf = pack_pair(ds[2 * ks], ds[2 * ks + 1]);
+#pragma unroll
+      for (int f = 0; f < C::NFRAG; ++f) dq[f] = mfma16(frag_cols<HD>(Ks, 32 * ks, f, i16, g), dsf, dq[f]);
+    }
+  }
+  bf16* drow = dqkv + ((long)b * L + q0 + i16) * ld + h * HD;
+#pragma unroll
+  for (int f = 0; f < C::NFRAG; ++f) {
+    int d = 16 * f + 4 * g;
+    if (d < HD) {
+      bf16x4 v;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = f2bf(dq[f][r]);
+      *(bf16x4*)(drow + d) = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward dK, dV: grid (L/64, B*H); wave owns 16 keys, loops over query blocks.
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
+                                                           const float* __restrict__ lse, const float* __restrict__ delta,
+                                                           bf16* __restrict__ dqkv, int L, int H, float scale,
+                                                           float scale_log2e) {
+  using C = AttnCfg<HD>;
+  __shared__ __attribute__((aligned(16))) char smem[2 * C::TILE_BYTES + 512];
+  char* Qs = smem;
+  char* dOs = smem + C::TILE_BYTES;
+  float* lse_s = (float*)(smem + 2 * C::TILE_BYTES);
+  float* del_s = lse_s + 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / H, h = bh - b * H;
+  const int D = H * HD;
+  const long ld = 3L * D;
+  const int k0 = blockIdx.x * 64 + wave * 16;
+  const bf16* base = qkv + (long)b * L * ld + h * HD;
+
+  zero_pad<HD>(Qs, tid);
+  zero_pad<HD>(dOs, tid);
+
+  bf16x8 kf[C::KSTEPS], vf[C::KSTEPS];
+  load_frag_global<HD>(kf, base + (long)(k0 + i16) * ld + D, g);
+  load_frag_global<HD>(vf, base + (long)(k0 + i16) * ld + 2 * D, g);
+
+  f32x4 dk[C::NFRAG], dv[C::NFRAG];
+#pragma unroll
+  for (int f = 0; f < C::NFRAG; ++f) {
+    dk[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dv[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  for (int qb = 0; qb < L; qb += 64) {
+    __syncthreads();
+    stage_tile<HD>(Qs, base + (long)qb * ld, ld, tid);
+    stage_tile<HD>(dOs, dout + ((long)b * L + qb) * D + h * HD, D, tid);
+    if (tid < 64) lse_s[tid] = lse[(long)bh * L + qb + tid];
+    else if (tid < 128) del_s[tid - 64] = delta[(long)bh * L + qb + tid - 64];
+    __syncthreads();
+    // S fragments: rows = queries 16f + 4g + r, col = key i16
+    f32x4 pm[4], ds[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < C::KSTEPS; ++ks) {
+        s = mfma16(frag_rows<HD>(Qs, 16 * f + i16, ks, g), kf[ks], s);
+        dp = mfma16(frag_rows<HD>(dOs, 16 * f + i16, ks, g), vf[ks], dp);
+      }
+      f32x4 ls = *(const f32x4*)(lse_s + 16 * f + 4 * g);
+      f32x4 dl = *(const f32x4*)(del_s + 16 * f + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float pv = exp2f(s[r] * scale_log2e - ls[r]);
+        pm[f][r] = pv;
+        ds[f][r] = pv * (dp[r] - dl[r]) * scale;
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 pf = pack_pair(pm[2 * ks], pm[2 * ks + 1]);
+      bf16x8 dsf = pack_pair(ds[2 * ks], ds[2 * ks + 1]);
+#pragma unroll
+      for (int f = 0; f < C::NFRAG; ++f) {
+        dv[f] = mfma16(frag_cols<HD>(dOs, 32 * ks, f, i16, g), pf, dv[f]);
+        dk[f] = mfma16(frag_cols<HD>(Qs, 32 * ks, f, i16, g), dsf, dk[f]);
+      }
+    }
+  }
+  bf16* drow = dqkv + ((long)b * L + k0 + i16) * ld + h * HD;
+#pragma unroll
+  for (int f = 0; f < C::NFRAG; ++f) {
+    int d = 16 * f + 4 * g;
+    if (d < HD) {
+      bf16x4 a, c;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        a[r] = f2bf(dk[f][r]);
+        c[r] = f2bf(dv[f][r]);
+      }
+      *(bf16x4*)(drow + D + d) = a;
+      *(bf16x4*)(drow + 2 * D + d) = c;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+
+#define ATTN_DISPATCH(HD_, CALL) \
+  switch (HD_) {                 \
+    case 32: { constexpr int HDc = 32; CALL; } break; \
+    case 64: { constexpr int HDc = 64; CALL; } break; \
+    case 72: { constexpr int HDc = 72; CALL; } break; \
+    case 80: { constexpr int HDc = 80; CALL; } break; \
+    default: mdt_set_error("attention: head_dim must be one of 32, 64, 72, 80"); return MDT_ERR_ARG; \
+  }
+
+extern "C" int mdt_attn_fwd(const mdt_bf16* qkv, mdt_bf16* out, float* lse, int B, int L, int H, int hd,
+                            mdt_stream_t stream) {
+  MDT_REQUIRE(qkv && out && lse, "attn_fwd: null pointer");
+  MDT_REQUIRE(B > 0 && H > 0 && L > 0 && L % 64 == 0, "attn_fwd: L must be a positive multiple of 64");
+  float sl = (1.0f / sqrtf((float)hd)) * 1.4426950408889634f;
+  dim3 grid(L / 64, B * H);
+  ATTN_DISPATCH(hd, hipLaunchKernelGGL(attn_fwd_kernel<HDc>, grid, dim3(256), 0, (hipStream_t)stream,
+                                       (const bf16*)qkv, (bf16*)out, lse, L, H, sl));
+  return mdt_check_launch("attn_fwd");
+}
+
+extern "C" int mdt_attn_bwd(const mdt_bf16* qkv, const mdt_bf16* out, const mdt_bf16* dout, const float* lse,
+                            float* delta, mdt_bf16* dqkv, int B, int L, int H, int hd, mdt_stream_t stream) {
+  MDT_REQUIRE(qkv && out && dout && lse && delta && dqkv, "attn_bwd: null pointer");
+  MDT_REQUIRE(B > 0 && H > 0 && L > 0 && L % 64 == 0, "attn_bwd: L must be a positive multiple of 64");
+  float sc = 1.0f / sqrtf((float)hd);
+  float sl = sc * 1.4426950408889634f;
+  dim3 grid(L / 64, B * H);
+  ATTN_DISPATCH(hd, hipLaunchKernelGGL(attn_bwd_dq_kernel<HDc>, grid, dim3(256), 0, (hipStream_t)stream,
+                                       (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta,
+                                       (bf16*)dqkv, L, H, sc, sl));
+  int rc = mdt_check_launch("attn_bwd_dq");
+  if (rc) return rc;
+  ATTN_DISPATCH(hd, hipLaunchKernelGGL(attn_bwd_dkv_kernel<HDc>, grid, dim3(256), 0, (hipStream_t)stream,
+                                       (const bf16*)qkv, (const bf16*)dout, lse, delta, (bf16*)dqkv, L, H, sc, sl));
+  return mdt_check_launch("attn_bwd_dkv");
+}

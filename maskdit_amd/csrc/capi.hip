@@ -1,0 +1,86 @@
+// Error plumbing, hipGraph capture helpers and HIP-event timing for the C ABI.
+#include "common.h"
+#include "../../include/maskdit_hip.h"
+#include <string.h>
+#include <stdio.h>
+
+static thread_local char g_err[512] = "";
+
+void mdt_set_error(const char* msg) {
+  strncpy(g_err, msg ? msg : "", sizeof(g_err) - 1);
+  g_err[sizeof(g_err) - 1] = 0;
+}
+
+int mdt_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: launch failed: %s", what, hipGetErrorString(e));
+    return MDT_ERR_LAUNCH;
+  }
+  return MDT_OK;
+}
+
+extern "C" const char* mdt_last_error(void) { return g_err; }
+extern "C" int mdt_version(void) { return 1; }
+
+#define HIP_TRY(call, what)                                                         \
+  do {                                                                              \
+    hipError_t e_ = (call);                                                         \
+    if (e_ != hipSuccess) {                                                         \
+      snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e_));        \
+      return MDT_ERR_LAUNCH;                                                        \
+    }                                                                               \
+  } while (0)
+
+extern "C" int mdt_graph_begin(mdt_stream_t stream) {
+  HIP_TRY(hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal), "graph_begin");
+  return MDT_OK;
+}
+
+extern "C" int mdt_graph_end(mdt_stream_t stream, void** graph_exec_out) {
+  MDT_REQUIRE(graph_exec_out, "graph_end: null out");
+  hipGraph_t graph = nullptr;
+  HIP_TRY(hipStreamEndCapture((hipStream_t)stream, &graph), "graph_end");
+  hipGraphExec_t exec = nullptr;
+  hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  hipGraphDestroy(graph);
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "graph_instantiate: %s", hipGetErrorString(e));
+    return MDT_ERR_LAUNCH;
+  }
+  *graph_exec_out = (void*)exec;
+  return MDT_OK;
+}
+
+extern "C" int mdt_graph_launch(void* graph_exec, mdt_stream_t stream) {
+  MDT_REQUIRE(graph_exec, "graph_launch: null graph");
+  HIP_TRY(hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream), "graph_launch");
+  return MDT_OK;
+}
+
+extern "C" int mdt_graph_destroy(void* graph_exec) {
+  if (graph_exec) HIP_TRY(hipGraphExecDestroy((hipGraphExec_t)graph_exec), "graph_destroy");
+  return MDT_OK;
+}
+
+extern "C" int mdt_event_create(void** ev) {
+  MDT_REQUIRE(ev, "event_create: null out");
+  hipEvent_t e;
+  HIP_TRY(hipEventCreate(&e), "event_create");
+  *ev = (void*)e;
+  return MDT_OK;
+}
+extern "C" int mdt_event_record(void* ev, mdt_stream_t stream) {
+  HIP_TRY(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream), "event_record");
+  return MDT_OK;
+}
+extern "C" int mdt_event_elapsed_ms(void* start, void* stop, float* ms) {
+  MDT_REQUIRE(ms, "event_elapsed: null out");
+  HIP_TRY(hipEventSynchronize((hipEvent_t)stop), "event_sync");
+  HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop), "event_elapsed");
+  return MDT_OK;
+}
+extern "C" int mdt_event_destroy(void* ev) {
+  if (ev) HIP_TRY(hipEventDestroy((hipEvent_t)ev), "event_destroy");
+  return MDT_OK;
+}

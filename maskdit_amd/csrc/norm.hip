@@ -1,0 +1,283 @@
+// HBM-bound glue around the GEMMs: LayerNorm + adaLN modulate (fwd / bwd), gated-residual
+// backward, bias-gradient column sums.  All row-wise kernels are one wave per row with
+// 16-byte vector accesses; per-sample reductions (d shift / d scale / d gate, shape [B, D])
+// are accumulated per lane in registers across the rows a workgroup owns, then combined
+// through LDS and one f32 atomic per column per workgroup.
+//
+// Reference: modulate (models/maskdit.py:19-20), LayerNorm(eps 1e-6, no affine) (:177,179),
+// `x + gate.unsqueeze(1) * f(...)` (:190-191); backward = what autograd derives for them.
+#include "common.h"
+#include "../../include/maskdit_hip.h"
+
+#define MAXV 5  // up to 5 float4 per lane => D <= 1280
+
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ln_modulate_fwd_kernel(const float* __restrict__ x, const float* __restrict__ shift,
+                                                              const float* __restrict__ scale, int mod_ld,
+                                                              int rows_per_sample, bf16* __restrict__ xn,
+                                                              float* __restrict__ stats, int M, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nv = D >> 2;
+  const float* xr = x + (long)row * D;
+  f32x4 v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    int c = lane + 64 * i;
+    if (c < nv) {
+      v[i] = *(const f32x4*)(xr + 4 * c);
+      s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+    }
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    int c = lane + 64 * i;
+    if (c < nv) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float d = v[i][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-6f);
+  const long b = row / rows_per_sample;
+  const float* sh = shift + b * mod_ld;
+  const float* sc = scale + b * mod_ld;
+  bf16* o = xn + (long)row * D;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    int c = lane + 64 * i;
+    if (c < nv) {
+      f32x4 a = *(const f32x4*)(sh + 4 * c), m = *(const f32x4*)(sc + 4 * c);
+      bf16x4 r;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) r[e] = f2bf((v[i][e] - mean) * rstd * (1.f + m[e]) + a[e]);
+      *(bf16x4*)(o + 4 * c) = r;
+    }
+  }
+  if (lane == 0) {
+    stats[2 * (long)row] = mean;
+    stats[2 * (long)row + 1] = rstd;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// grid (B, splits): workgroup handles rows [s*chunk, (s+1)*chunk) of sample b, 4 waves.
+__global__ __launch_bounds__(256) void ln_modulate_bwd_kernel(const bf16* __restrict__ dxn, const float* __restrict__ x,
+                                                              const float* __restrict__ stats, const float* __restrict__ scale,
+                                                              int mod_ld, int rows_per_sample, int chunk,
+                                                              float* __restrict__ dx, int accumulate,
+                                                              float* __restrict__ dshift, float* __restrict__ dscale,
+                                                              int dmod_ld, int D) {
+  __shared__ float red[2][4][MAXV * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x;
+  const int r_begin = blockIdx.y * chunk, r_end = min(r_begin + chunk, rows_per_sample);
+  const int nv = D >> 2;
+  const float* sc = scale + (long)b * mod_ld;
+  f32x4 scl[MAXV], a_sh[MAXV], a_sc[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    int c = lane + 64 * i;
+    a_sh[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    a_sc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    scl[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (c < nv) {
+      f32x4 t = *(const f32x4*)(sc + 4 * c);
+      scl[i] = (f32x4){1.f + t[0], 1.f + t[1], 1.f + t[2], 1.f + t[3]};
+    }
+  }
+  const float invD = 1.f / (float)D;
+  for (int r = r_begin + wave; r < r_end; r += 4) {
+    const long row = (long)b * rows_per_sample + r;
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    const float* xr = x + row * D;
+    const bf16* gr = dxn + row * D;
+    f32x4 xh[MAXV], gm[MAXV];
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      int c = lane + 64 * i;
+      if (c < nv) {
+        f32x4 xv = *(const f32x4*)(xr + 4 * c);
+        bf16x4 gv = *(const bf16x4*)(gr + 4 * c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float gg = bf2f(gv[e]);
+          float h = (xv[e] - mean) * rstd;
+          a_sh[i][e] += gg;
+          a_sc[i][e] += gg * h;
+          float gmod = gg * scl[i][e];
+          xh[i][e] = h;
+          gm[i][e] = gmod;
+          c1 += gmod;
+          c2 += gmod * h;
+        }
+      }
+    }
+    c1 = wave_sum(c1) * invD;
+    c2 = wave_sum(c2) * invD;
+    float* dr = dx + row * D;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      int c = lane + 64 * i;
+      if (c < nv) {
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rstd * (gm[i][e] - c1 - xh[i][e] * c2);
+        if (accumulate) {
+          f32x4 p = *(const f32x4*)(dr + 4 * c);
+          o[0] += p[0]; o[1] += p[1]; o[2] += p[2]; o[3] += p[3];
+        }
+        *(f32x4*)(dr + 4 * c) = o;
+      }
+    }
+  }
+  // combine the 4 waves' per-column partials, one atomic per column per workgroup
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    int c = lane + 64 * i;
+    if (c < nv) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        red[0][wave][4 * c + e] = a_sh[i][e];
+        red[1][wave][4 * c + e] = a_sc[i][e];
+      }
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float s0 = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+    float s1 = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+    atomic_add_f32(dshift + (long)b * dmod_ld + c, s0);
+    atomic_add_f32(dscale + (long)b * dmod_ld + c, s1);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// grid (B, splits, column blocks of 1024): thread owns a float4 column quad, loops over rows.
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dx, const bf16* __restrict__ y,
+                                                       const float* __restrict__ gate, int mod_ld, int rows_per_sample,
+                                                       int chunk, bf16* __restrict__ dys, float* __restrict__ dgate,
+                                                       int dmod_ld, float* __restrict__ dbias, int D) {
+  const int b = blockIdx.x;
+  const int cq = blockIdx.z * 256 + threadIdx.x;
+  if (cq * 4 >= D) return;
+  const int r_begin = blockIdx.y * chunk, r_end = min(r_begin + chunk, rows_per_sample);
+  const f32x4 g = *(const f32x4*)(gate + (long)b * mod_ld + 4 * cq);
+  f32x4 ag = (f32x4){0.f, 0.f, 0.f, 0.f}, ab = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int r = r_begin; r < r_end; ++r) {
+    const long off = ((long)b * rows_per_sample + r) * D + 4 * cq;
+    f32x4 d = *(const f32x4*)(dx + off);
+    bf16x4 yv = *(const bf16x4*)(y + off);
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ag[e] += d[e] * bf2f(yv[e]);
+      o[e] = f2bf(d[e] * g[e]);
+      ab[e] += bf2f(o[e]);
+    }
+    *(bf16x4*)(dys + off) = o;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    atomic_add_f32(dgate + (long)b * dmod_ld + 4 * cq + e, ag[e]);
+    if (dbias) atomic_add_f32(dbias + 4 * cq + e, ab[e]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// out[n] += sum_m in[m, n]; grid (N/256 column blocks of 256, row chunks); 256 threads =
+// 32 column octets x 8 row lanes.
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16* __restrict__ in, int ld, float* __restrict__ out,
+                                                          int M, int N, int rows_per_block) {
+  __shared__ float red[8][256];
+  const int co = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int n = blockIdx.x * 256 + co * 8;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(r0 + rows_per_block, M);
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  if (n < N) {
+    for (int r = r0 + rl; r < r1; r += 8) {
+      bf16x8 v = *(const bf16x8*)(in + (long)r * ld + n);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[rl][co * 8 + e] = acc[e];
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (blockIdx.x * 256 + c < N) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += red[k][c];
+    atomic_add_f32(out + blockIdx.x * 256 + c, s);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+
+static int pick_chunk(int B, int rows_per_sample) {
+  // enough workgroups to fill 256 CUs a few times over without shredding the per-sample sums
+  int splits = 1;
+  while (B * splits < 2048 && rows_per_sample / (splits * 2) >= 8) splits *= 2;
+  return cdiv(rows_per_sample, splits);
+}
+
+extern "C" int mdt_ln_modulate_fwd(const float* x, const float* shift, const float* scale, int mod_ld,
+                                   int rows_per_sample, mdt_bf16* xn, float* stats, int M, int D,
+                                   mdt_stream_t stream) {
+  MDT_REQUIRE(x && shift && scale && xn && stats, "ln_modulate_fwd: null pointer");
+  MDT_REQUIRE(D % 4 == 0 && D <= MAXV * 256, "ln_modulate_fwd: D must be a multiple of 4 and <= 1280");
+  MDT_REQUIRE(M > 0 && rows_per_sample > 0 && M % rows_per_sample == 0, "ln_modulate_fwd: M must be B*rows_per_sample");
+  hipLaunchKernelGGL(ln_modulate_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, shift, scale,
+                     mod_ld, rows_per_sample, (bf16*)xn, stats, M, D);
+  return mdt_check_launch("ln_modulate_fwd");
+}
+
+extern "C" int mdt_ln_modulate_bwd(const mdt_bf16* dxn, const float* x, const float* stats, const float* scale,
+                                   int mod_ld, int rows_per_sample, float* dx, int accumulate, float* dshift,
+                                   float* dscale, int dmod_ld, int M, int D, mdt_stream_t stream) {
+  MDT_REQUIRE(dxn && x && stats && scale && dx && dshift && dscale, "ln_modulate_bwd: null pointer");
+  MDT_REQUIRE(D % 4 == 0 && D <= MAXV * 256, "ln_modulate_bwd: D must be a multiple of 4 and <= 1280");
+  MDT_REQUIRE(M > 0 && rows_per_sample > 0 && M % rows_per_sample == 0, "ln_modulate_bwd: M must be B*rows_per_sample");
+  int B = M / rows_per_sample;
+  int chunk = pick_chunk(B, rows_per_sample);
+  dim3 grid(B, cdiv(rows_per_sample, chunk));
+  hipLaunchKernelGGL(ln_modulate_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dxn, x, stats,
+                     scale, mod_ld, rows_per_sample, chunk, dx, accumulate, dshift, dscale, dmod_ld, D);
+  return mdt_check_launch("ln_modulate_bwd");
+}
+
+extern "C" int mdt_gate_bwd(const float* dx, const mdt_bf16* y, const float* gate, int mod_ld, int rows_per_sample,
+                            mdt_bf16* dys, float* dgate, int dmod_ld, float* dbias, int M, int D,
+                            mdt_stream_t stream) {
+  MDT_REQUIRE(dx && y && gate && dys && dgate, "gate_bwd: null pointer");
+  MDT_REQUIRE(D % 4 == 0, "gate_bwd: D must be a multiple of 4");
+  MDT_REQUIRE(M > 0 && rows_per_sample > 0 && M % rows_per_sample == 0, "gate_bwd: M must be B*rows_per_sample");
+  int B = M / rows_per_sample;
+  int chunk = pick_chunk(B, rows_per_sample);
+  dim3 grid(B, cdiv(rows_per_sample, chunk), cdiv(D / 4, 256));
+  hipLaunchKernelGGL(gate_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dx, (const bf16*)y, gate, mod_ld,
+                     rows_per_sample, chunk, (bf16*)dys, dgate, dmod_ld, dbias, D);
+  return mdt_check_launch("gate_bwd");
+}
+
+extern "C" int mdt_colsum_bf16(const mdt_bf16* in, int ld, float* out, int M, int N, mdt_stream_t stream) {
+  MDT_REQUIRE(in && out, "colsum: null pointer");
+  MDT_REQUIRE(M > 0 && N > 0 && N % 8 == 0 && ld % 8 == 0, "colsum: N and ld must be multiples of 8");
+  int col_blocks = cdiv(N, 256);
+  int row_blocks = 1;
+  while (col_blocks * row_blocks < 1024 && M / (row_blocks * 2) >= 64) row_blocks *= 2;
+  int rpb = cdiv(M, row_blocks);
+  dim3 grid(col_blocks, cdiv(M, rpb));
+  hipLaunchKernelGGL(colsum_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)in, ld, out, M, N, rpb);
+  return mdt_check_launch("colsum");
+}

@@ -1,0 +1,583 @@
+"""MaskDiT engine: flat parameter arenas + pre-bound launch plans over libmaskdit_hip.so.
+
+Design (MI355X-first):
+  * every trainable tensor of the reference state dict is a VIEW into one fp32 arena (same
+    names / shapes as the reference checkpoint); gradients, Adam moments
+    and the EMA live in arenas of the same layout, so the optimizer + EMA + bf16-shadow refresh
+    is ONE streaming kernel and the DP gradient all-reduce works on contiguous slabs;
+  * all adaLN modulation Linears (28 + 8 + 2 of them, each fed by the same SiLU(c)) are laid
+    out contiguously so the forward needs ONE [B, D] x [N_mod, D]^T GEMM for every
+    shift/scale/gate of the network, and the backward one dgrad + one wgrad GEMM;
+  * GEMM operands are bf16 shadows of the fp32 master weights (N-major for forward,
+    K-major transposed copies for the data-gradient GEMMs), refreshed by the optimizer;
+  * a forward / backward pass is a *plan*: a list of (C entry point, pre-marshalled args) built
+    once per (batch, mode) over preallocated HBM buffers -- replaying it is a tight loop of
+    ctypes calls with no allocation, which also makes it hipGraph-capturable (sampler).
+
+Reference semantics: DiT.forward / forward_encoder (models/maskdit.py:467-557), DiTBlock
+(:170-192), DecoderLayer (:195-213), FinalLayer (:216-234), EDMPrecond (:756-773), EDMLoss
+(train_utils/loss.py:28-60).  Backward = hand-derived gradients of the same graph.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GATE_RES, EPI_GELU, EPI_SILU, GemmNTArgs,
+                   GemmTNArgs)
+
+DEC_HIDDEN, DEC_DEPTH, DEC_HEADS = 512, 8, 16  # models/maskdit.py:310-312
+MODEL_CONFIGS = {  # models/maskdit.py:649-715  name -> (depth, hidden, patch, heads)
+    'DiT-H/2': (32, 1280, 2, 16), 'DiT-H/4': (32, 1280, 4, 16), 'DiT-H/8': (32, 1280, 8, 16),
+    'DiT-XL/2': (28, 1152, 2, 16), 'DiT-XL/4': (28, 1152, 4, 16), 'DiT-XL/8': (28, 1152, 8, 16),
+    'DiT-L/2': (24, 1024, 2, 16), 'DiT-L/4': (24, 1024, 4, 16), 'DiT-L/8': (24, 1024, 8, 16),
+    'DiT-B/2': (12, 768, 2, 12), 'DiT-B/4': (12, 768, 4, 12), 'DiT-B/8': (12, 768, 8, 12),
+    'DiT-S/2': (12, 384, 2, 6), 'DiT-S/4': (12, 384, 4, 6), 'DiT-S/8': (12, 384, 8, 6),
+}
+YPAD = 1024  # label one-hot width padded to a multiple of 128 for the GEMMs
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class Spec:
+    model_type: str
+    depth: int
+    D: int
+    heads: int
+    patch: int
+    R: int
+    C: int
+    num_classes: int
+    mae: bool
+    Dd: int = DEC_HIDDEN
+    ddepth: int = DEC_DEPTH
+    dheads: int = DEC_HEADS
+
+    @property
+    def T(self):
+        return (self.R // self.patch) ** 2
+
+    @property
+    def hd(self):
+        return self.D // self.heads
+
+    @property
+    def dhd(self):
+        return self.Dd // self.dheads
+
+    @property
+    def pp(self):
+        return self.patch * self.patch * self.C
+
+    @property
+    def n_mod(self):
+        return self.depth * 6 * self.D + self.ddepth * 6 * self.Dd + 2 * self.D + 2 * self.Dd
+
+    def mod_off(self, kind, i=0):
+        """Row offset of an adaLN Linear inside the stacked [N_mod, D] weight."""
+        if kind == 'enc':
+            return i * 6 * self.D
+        base = self.depth * 6 * self.D
+        if kind == 'dec':
+            return base + i * 6 * self.Dd
+        base += self.ddepth * 6 * self.Dd
+        if kind == 'dl':
+            return base
+        return base + 2 * self.D  # final
+
+
+def make_spec(model_type, img_resolution, img_channels, num_classes, use_decoder=True, mae_loss_coef=0.1):
+    if model_type not in MODEL_CONFIGS:
+        raise ValueError(f'unknown model_type {model_type}')
+    if not use_decoder:
+        raise NotImplementedError('maskdit_amd accelerates the shipped configuration (use_decoder=True) only')
+    depth, D, p, heads = MODEL_CONFIGS[model_type]
+    sp = Spec(model_type, depth, D, heads, p, img_resolution, img_channels, num_classes, mae_loss_coef > 0)
+    if sp.hd not in (32, 64, 72, 80):
+        raise NotImplementedError(f'head_dim {sp.hd} unsupported')
+    if sp.pp > 16 or sp.num_classes > YPAD or sp.num_classes <= 0:
+        raise NotImplementedError('patch vector > 16 elements or num_classes outside (0, 1024]')
+    T = sp.T
+    if T & (T - 1) or T > 1024 or T % 64:
+        raise NotImplementedError(f'token count {T} must be a power of two in [64, 1024]')
+    return sp
+
+
+# ------------------------------------------------------------------------------------------
+# parameter layout
+
+def param_table(sp: Spec) -> List[Tuple[str, tuple]]:
+    """(state-dict key, shape) for every TRAINABLE tensor, in arena order."""
+    D, Dd = sp.D, sp.Dd
+    ada_w, ada_b, rest = [], [], []
+
+    def ada(prefix, n):
+        ada_w.append((f'{prefix}.adaLN_modulation.1.weight', (n, D)))
+        ada_b.append((f'{prefix}.adaLN_modulation.1.bias', (n,)))
+
+    def block(prefix, W):
+        h = 4 * W
+        rest.extend([(f'{prefix}.attn.qkv.weight', (3 * W, W)), (f'{prefix}.attn.qkv.bias', (3 * W,)),
+                     (f'{prefix}.attn.proj.weight', (W, W)), (f'{prefix}.attn.proj.bias', (W,)),
+                     (f'{prefix}.mlp.fc1.weight', (h, W)), (f'{prefix}.mlp.fc1.bias', (h,)),
+                     (f'{prefix}.mlp.fc2.weight', (W, h)), (f'{prefix}.mlp.fc2.bias', (W,))])
+
+    for i in range(sp.depth):
+        ada(f'model.blocks.{i}', 6 * D)
+        block(f'model.blocks.{i}', D)
+    for i in range(sp.ddepth):
+        ada(f'model.decoder_blocks.{i}', 6 * Dd)
+        block(f'model.decoder_blocks.{i}', Dd)
+    ada('model.decoder_layer', 2 * D)
+    ada('model.final_layer', 2 * Dd)
+    rest.extend([('model.decoder_layer.linear.weight', (Dd, D)), ('model.decoder_layer.linear.bias', (Dd,)),
+                 ('model.final_layer.linear.weight', (sp.pp, Dd)), ('model.final_layer.linear.bias', (sp.pp,)),
+                 ('model.x_embedder.proj.weight', (D, sp.C, sp.patch, sp.patch)), ('model.x_embedder.proj.bias', (D,)),
+                 ('model.t_embedder.mlp.0.weight', (D, 256)), ('model.t_embedder.mlp.0.bias', (D,)),
+                 ('model.t_embedder.mlp.2.weight', (D, D)), ('model.t_embedder.mlp.2.bias', (D,)),
+                 ('model.y_embedder.embedding_table.weight', (D, sp.num_classes))])
+    if sp.mae:
+        rest.append(('model.mask_token', (1, 1, Dd)))
+    return ada_w + ada_b + rest
+
+
+class Layout:
+    """Offsets (in elements) of every trainable tensor inside the flat arenas."""
+
+    def __init__(self, sp: Spec):
+        self.sp = sp
+        self.off: Dict[str, int] = {}
+        self.shape: Dict[str, tuple] = {}
+        o = 0
+        for name, shp in param_table(sp):
+            n = int(np.prod(shp))
+            self.off[name] = o
+            self.shape[name] = shp
+            o += _rup(n, 8)  # adaLN tensors are multiples of 8 elements, so their stacks stay dense
+        self.n = _rup(o, 8)
+        self.ada_w = self.off['model.blocks.0.adaLN_modulation.1.weight']
+        self.ada_b = self.off['model.blocks.0.adaLN_modulation.1.bias']
+        # K-major (transposed) shadows for the data-gradient GEMMs
+        self.t_off: Dict[str, int] = {}
+        self.t_entries: List[Tuple[int, int, int, int]] = []
+        to = 0
+
+        def addT(key, src, rows, cols):
+            nonlocal to
+            self.t_off[key] = to
+            self.t_entries.append((src, to, rows, cols))
+            to += _rup(rows * cols, 8)
+
+        addT('ada', self.ada_w, sp.n_mod, sp.D)
+        for name, shp in param_table(sp):
+            if name.endswith(('attn.qkv.weight', 'attn.proj.weight', 'mlp.fc1.weight', 'mlp.fc2.weight')) \
+                    or name in ('model.decoder_layer.linear.weight', 'model.t_embedder.mlp.2.weight'):
+                addT(name, self.off[name], shp[0], shp[1])
+        self.nt = to
+        # block-wise slabs of the arena for gradient all-reduce overlap (name -> (start, end))
+        self.slabs: Dict[str, Tuple[int, int]] = {}
+
+        def span(prefix_first, prefix_last_end_name):
+            return self.off[prefix_first], self.off[prefix_last_end_name] + _rup(int(np.prod(self.shape[prefix_last_end_name])), 8)
+
+        for i in range(sp.depth):
+            self.slabs[f'enc{i}'] = span(f'model.blocks.{i}.attn.qkv.weight', f'model.blocks.{i}.mlp.fc2.bias')
+        for i in range(sp.ddepth):
+            self.slabs[f'dec{i}'] = span(f'model.decoder_blocks.{i}.attn.qkv.weight', f'model.decoder_blocks.{i}.mlp.fc2.bias')
+        self.slabs['ada'] = (0, self.off['model.blocks.0.attn.qkv.weight'])
+        self.slabs['misc'] = (self.off['model.decoder_layer.linear.weight'], self.n)
+
+
+# ------------------------------------------------------------------------------------------
+# plans
+
+class Plan:
+    """A replayable list of pre-marshalled launches (and optional python callbacks)."""
+
+    def __init__(self):
+        self.calls: list = []
+        self.keep: list = []
+
+    def add(self, name, *args):
+        fn = getattr(_lib.lib(), name)
+        self.calls.append((fn, args, name))
+
+    def add_callback(self, cb: Callable[[], None]):
+        self.calls.append((None, cb, 'callback'))
+
+    def run(self, stream: int):
+        for fn, args, name in self.calls:
+            if fn is None:
+                args()
+                continue
+            rc = fn(*args, stream)
+            if rc != 0:
+                raise _lib.MaskDiTLibError(f'{name} failed ({rc}): {_lib.lib().mdt_last_error().decode()}')
+
+
+class Engine:
+    """Owns arenas, shadows and launch plans for one EDMPrecond/DiT instance on one GPU."""
+
+    def __init__(self, sp: Spec, device):
+        self.sp = sp
+        self.device = torch.device(device)
+        if self.device.type != 'cuda':
+            raise _lib.MaskDiTLibError('maskdit_amd.Engine needs a CUDA/HIP device: there is no CPU path')
+        _lib.lib()
+        self.lay = Layout(sp)
+        dev = self.device
+        self.P = torch.zeros(self.lay.n, device=dev, dtype=torch.float32)
+        self.G: Optional[torch.Tensor] = None
+        self.W16 = torch.zeros(self.lay.n, device=dev, dtype=torch.bfloat16)
+        self.WT16 = torch.zeros(self.lay.nt, device=dev, dtype=torch.bfloat16)
+        self.Wy16 = torch.zeros(sp.D, YPAD, device=dev, dtype=torch.bfloat16)
+        self.pos = torch.zeros(sp.T, sp.D, device=dev, dtype=torch.float32)
+        self.dpos = torch.zeros(sp.T, sp.Dd, device=dev, dtype=torch.float32)
+        tab, tiles = [], 0
+        for src, dst, rows, cols in self.lay.t_entries:
+            tab += [src, dst, rows, cols, tiles]
+            tiles += ((rows + 63) // 64) * ((cols + 63) // 64)
+        self._t_table = torch.tensor(tab, dtype=torch.int64, device=dev)
+        self._t_tiles = tiles
+        self.shadows_dirty = True
+        self._plans: Dict[tuple, 'PassPlan'] = {}
+        self.grad_slab_hook: Optional[Callable[[str, int, int], None]] = None  # DP overlap (ddp.py)
+
+    # ---- arenas ------------------------------------------------------------------------
+    def view(self, arena: torch.Tensor, name: str) -> torch.Tensor:
+        o, shp = self.lay.off[name], self.lay.shape[name]
+        return arena[o:o + int(np.prod(shp))].view(shp)
+
+    def ensure_grad(self) -> torch.Tensor:
+        if self.G is None:
+            self.G = torch.zeros(self.lay.n, device=self.device, dtype=torch.float32)
+        return self.G
+
+    def refresh_shadows(self, cast: bool = True):
+        """bf16 N-major shadow (optional: the optimizer already wrote it), K-major transposes,
+        padded label table."""
+        st = torch.cuda.current_stream().cuda_stream
+        sp, lay = self.sp, self.lay
+        if cast:
+            _lib.call('mdt_cast_f32_bf16', self.P.data_ptr(), lay.n, self.W16.data_ptr(), lay.n, 1, lay.n, 0, st)
+        _lib.call('mdt_transpose_bf16_batched', self.W16.data_ptr(), self.WT16.data_ptr(), self._t_table.data_ptr(),
+                  len(lay.t_entries), self._t_tiles, st)
+        yo = lay.off['model.y_embedder.embedding_table.weight']
+        _lib.call('mdt_cast_f32_bf16', self.P.data_ptr() + 4 * yo, sp.num_classes, self.Wy16.data_ptr(), YPAD, sp.D,
+                  sp.num_classes, 0, st)
+        self.shadows_dirty = False
+
+    # ---- plans -------------------------------------------------------------------------
+    def plan(self, B: int, masked: bool, train: bool, L: Optional[int] = None) -> 'PassPlan':
+        key = (B, masked, train, L)
+        pl = self._plans.get(key)
+        if pl is None:
+            if len(self._plans) >= 4:  # buffers are large: keep few shapes alive
+                self._plans.pop(next(iter(self._plans)))
+            pl = PassPlan(self, B, masked, train, L)
+            self._plans[key] = pl
+        return pl
+
+    def release_plans(self):
+        self._plans.clear()
+
+
+def _nt(A, lda, Bw, ldb, M, N, K, bias=0, epi=EPI_BF16, out=0, ldo=0, out2=0, ldo2=0, outf=0, ldof=0, res=0, ldres=0,
+        gate=0, gate_ld=0, rps=1, aux=0, ldaux=0):
+    a = GemmNTArgs()
+    a.A, a.lda, a.B, a.ldb, a.M, a.N, a.K = A, lda, Bw, ldb, M, N, K
+    a.bias, a.epi = bias or None, epi
+    a.out, a.ldo, a.out2, a.ldo2 = out or None, ldo, out2 or None, ldo2
+    a.outf, a.ldof, a.res, a.ldres = outf or None, ldof, res or None, ldres
+    a.gate, a.gate_ld, a.rows_per_sample = gate or None, gate_ld, rps
+    a.aux, a.ldaux = aux or None, ldaux
+    return a
+
+
+def _tn(A, lda, Bm, ldb, M, N1, N2, Cc, ldc, n1v=0, n2v=0, splits=0):
+    a = GemmTNArgs()
+    a.A, a.lda, a.B, a.ldb, a.M, a.N1, a.N2 = A, lda, Bm, ldb, M, N1, N2
+    a.C, a.ldc, a.n1_valid, a.n2_valid, a.splits = Cc, ldc, n1v, n2v, splits
+    return a
+
+
+class PassPlan:
+    """Buffers + forward/backward launch lists for a fixed (batch, masked?, train?) shape."""
+
+    def __init__(self, eng: Engine, B: int, masked: bool, train: bool, L: Optional[int]):
+        sp = eng.sp
+        self.eng, self.B, self.masked, self.train = eng, B, masked, train
+        self.T = sp.T
+        self.L = (L if L is not None else sp.T // 2) if masked else sp.T
+        if self.L % 64:
+            raise NotImplementedError(f'kept-token count {self.L} must be a multiple of 64')
+        self.Bp = _rup(B, 64)
+        self.buf: Dict[str, torch.Tensor] = {}
+        self.fwd = Plan()
+        self.bwd = Plan()
+        self._build()
+
+    # ---- buffers -----------------------------------------------------------------------
+    def t(self, name, shape, dtype):
+        if name in self.buf:
+            return self.buf[name]
+        x = torch.zeros(shape, device=self.eng.device, dtype=dtype)
+        self.buf[name] = x
+        return x
+
+    def f32(self, name, *shape):
+        return self.t(name, shape, torch.float32)
+
+    def b16(self, name, *shape):
+        return self.t(name, shape, torch.bfloat16)
+
+    def _build(self):
+        eng, sp, lay = self.eng, self.eng.sp, self.eng.lay
+        B, Bp, T, L, D, Dd = self.B, self.Bp, self.T, self.L, sp.D, sp.Dd
+        NM = sp.n_mod
+        train = self.train
+        Pp, W16p, WTp = eng.P.data_ptr(), eng.W16.data_ptr(), eng.WT16.data_ptr()
+
+        def Pf(name):  # fp32 master pointer
+            return Pp + 4 * lay.off[name]
+
+        def Wp(name):  # bf16 N-major shadow pointer
+            return W16p + 2 * lay.off[name]
+
+        def WT(key):  # bf16 K-major shadow pointer
+            return WTp + 2 * lay.t_off[key]
+
+        f, g = self.fwd, self.bwd
+        # ---------------- inputs -----------------------------------------------------------
+        xin = self.f32('xin', B, sp.C, sp.R, sp.R)
+        cn = self.f32('c_noise', B)
+        lab = self.f32('labels', B, sp.num_classes)
+        ids32 = self.t('ids32', (B, 2 * T), torch.int32) if self.masked else None
+        Fx = self.f32('F', B, sp.C, sp.R, sp.R)
+        # ---------------- conditioning path ---------------------------------------------------
+        temb = self.b16('temb', Bp, 256)
+        h1, a1 = self.b16('h1', Bp, D), self.b16('a1', Bp, D)
+        c_t, c_y, c = self.f32('c_t', Bp, D), self.f32('c_y', Bp, D), self.f32('c', Bp, D)
+        lab16 = self.b16('lab16', Bp, YPAD)
+        sc16 = self.b16('sc16', Bp, D)
+        mod = self.f32('mod', Bp, NM)
+        f.add('mdt_timestep_embed', cn.data_ptr(), temb.data_ptr(), 256, B, 256)
+        f.add('mdt_gemm_nt', C.byref(self._k(_nt(temb.data_ptr(), 256, Wp('model.t_embedder.mlp.0.weight'), 256, B, D, 256,
+                                               bias=Pf('model.t_embedder.mlp.0.bias'), epi=EPI_SILU, out=h1.data_ptr(), ldo=D,
+                                               out2=a1.data_ptr(), ldo2=D))))
+        f.add('mdt_gemm_nt', C.byref(self._k(_nt(a1.data_ptr(), D, Wp('model.t_embedder.mlp.2.weight'), D, B, D, D,
+                                               bias=Pf('model.t_embedder.mlp.2.bias'), epi=EPI_F32, outf=c_t.data_ptr(), ldof=D))))
+        f.add('mdt_cast_f32_bf16', lab.data_ptr(), sp.num_classes, lab16.data_ptr(), YPAD, B, sp.num_classes, 0)
+        f.add('mdt_gemm_nt', C.byref(self._k(_nt(lab16.data_ptr(), YPAD, eng.Wy16.data_ptr(), YPAD, B, D, YPAD, epi=EPI_F32,
+                                               outf=c_y.data_ptr(), ldof=D))))
+        f.add('mdt_add_f32', c_t.data_ptr(), c_y.data_ptr(), c.data_ptr(), B * D)
+        f.add('mdt_cast_f32_bf16', c.data_ptr(), D, sc16.data_ptr(), D, B, D, 1)
+        f.add('mdt_gemm_nt', C.byref(self._k(_nt(sc16.data_ptr(), D, W16p + 2 * lay.ada_w, D, B, NM, D, bias=Pp + 4 * lay.ada_b,
+                                               epi=EPI_F32, outf=mod.data_ptr(), ldof=NM))))
+        # ---------------- encoder --------------------------------------------------------------
+        Me = B * L
+        x0 = self.f32('x_e0', Me, D)
+        f.add('mdt_patch_embed_fwd', xin.data_ptr(), None, Pf('model.x_embedder.proj.weight'),
+              Pf('model.x_embedder.proj.bias'), eng.pos.data_ptr(), ids32.data_ptr() if ids32 is not None else None,
+              2 * T, x0.data_ptr(), B, sp.C, sp.R, sp.patch, L, D)
+        xs_e = [x0]
+        for i in range(sp.depth):
+            xs_e.append(self._block_fwd(f'model.blocks.{i}', 'e', i, xs_e[-1], mod, sp.mod_off('enc', i), D, sp.heads, L, Me))
+        # ---------------- decoder layer + unmask ----------------------------------------------
+        odl = sp.mod_off('dl')
+        xnd = self.b16('xn_dl', Me, D)
+        st_dl = self.f32('st_dl', Me, 2)
+        xdec = self.b16('xdec', Me, Dd)
+        f.add('mdt_ln_modulate_fwd', xs_e[-1].data_ptr(), mod.data_ptr() + 4 * odl, mod.data_ptr() + 4 * (odl + D), NM, L,
+              xnd.data_ptr(), st_dl.data_ptr(), Me, D)
+        f.add('mdt_gemm_nt', C.byref(self._k(_nt(xnd.data_ptr(), D, Wp('model.decoder_layer.linear.weight'), D, Me, Dd, D,
+                                               bias=Pf('model.decoder_layer.linear.bias'), epi=EPI_BF16, out=xdec.data_ptr(), ldo=Dd))))
+        Md = B * T
+        xd0 = self.f32('x_d0', Md, Dd)
+        use_mt = self.masked and sp.mae
+        f.add('mdt_unmask_fwd', xdec.data_ptr(), (ids32.data_ptr() + 4 * T) if self.masked else None, 2 * T,
+              Pf('model.mask_token') if use_mt else None, eng.dpos.data_ptr(), xd0.data_ptr(), B, T, L, Dd)
+        xs_d = [xd0]
+        for i in range(sp.ddepth):
+            xs_d.append(self._block_fwd(f'model.decoder_blocks.{i}', 'd', i, xs_d[-1], mod, sp.mod_off('dec', i), Dd, sp.dheads, T, Md))
+        ofin = sp.mod_off('fin')
+        st_f = self.f32('st_f', Md, 2)
+        f.add('mdt_final_fwd', xs_d[-1].data_ptr(), mod.data_ptr() + 4 * ofin, mod.data_ptr() + 4 * (ofin + Dd), NM,
+              Pf('model.final_layer.linear.weight'), Pf('model.final_layer.linear.bias'), Fx.data_ptr(), st_f.data_ptr(),
+              B, T, Dd, sp.C, sp.patch)
+        if not train:
+            return
+        # =================== backward ===========================================================
+        G = eng.ensure_grad()
+        Gp = G.data_ptr()
+
+        def Gf(name):
+            return Gp + 4 * lay.off[name]
+
+        dF = self.f32('dF', B, sp.C, sp.R, sp.R)
+        dmod = self.f32('dmod', Bp, NM)
+        wmax = max(Me * D, Md * Dd)
+        dxe = self.f32('dx_e', Me, D)
+        dxd = self.f32('dx_d', Md, Dd)
+        ws = dict(dys=self.b16('ws_dys', wmax), dh=self.b16('ws_dh', 4 * wmax), dxn=self.b16('ws_dxn', wmax),
+                  dao=self.b16('ws_dao', wmax), dqkv=self.b16('ws_dqkv', 3 * wmax),
+                  delta=self.f32('ws_delta', max(B * sp.heads * L, B * sp.dheads * T)))
+        self._ws = ws
+        g.add_callback(lambda: dmod.zero_())
+        g.add('mdt_final_bwd', dF.data_ptr(), xs_d[-1].data_ptr(), st_f.data_ptr(), mod.data_ptr() + 4 * ofin,
+              mod.data_ptr() + 4 * (ofin + Dd), NM, Pf('model.final_layer.linear.weight'), dxd.data_ptr(),
+              Gf('model.final_layer.linear.weight'), Gf('model.final_layer.linear.bias'), dmod.data_ptr() + 4 * ofin,
+              dmod.data_ptr() + 4 * (ofin + Dd), NM, B, T, Dd, sp.C, sp.patch)
+        for i in reversed(range(sp.ddepth)):
+            self._block_bwd(f'model.decoder_blocks.{i}', 'd', i, xs_d[i], mod, dmod, sp.mod_off('dec', i), Dd, sp.dheads, T, Md,
+                            dxd, Gf)
+            self._slab(f'dec{i}')
+        dxdec = self.b16('dxdec', Me, Dd)
+        g.add('mdt_unmask_bwd', dxd.data_ptr(), ids32.data_ptr() if self.masked else None, 2 * T, dxdec.data_ptr(),
+              Gf('model.mask_token') if use_mt else None, B, T, L, Dd)
+        g.add('mdt_gemm_tn', C.byref(self._k(_tn(dxdec.data_ptr(), Dd, xnd.data_ptr(), D, Me, Dd, D,
+                                               Gf('model.decoder_layer.linear.weight'), D))))
+        g.add('mdt_colsum_bf16', dxdec.data_ptr(), Dd, Gf('model.decoder_layer.linear.bias'), Me, Dd)
+        g.add('mdt_gemm_nt', C.byref(self._k(_nt(dxdec.data_ptr(), Dd, WT('model.decoder_layer.linear.weight'), Dd, Me, D, Dd,
+                                               epi=EPI_BF16, out=ws['dxn'].data_ptr(), ldo=D))))
+        g.add('mdt_ln_modulate_bwd', ws['dxn'].data_ptr(), xs_e[-1].data_ptr(), st_dl.data_ptr(), mod.data_ptr() + 4 * (odl + D),
+              NM, L, dxe.data_ptr(), 0, dmod.data_ptr() + 4 * odl, dmod.data_ptr() + 4 * (odl + D), NM, Me, D)
+        for i in reversed(range(sp.depth)):
+            self._block_bwd(f'model.blocks.{i}', 'e', i, xs_e[i], mod, dmod, sp.mod_off('enc', i), D, sp.heads, L, Me, dxe, Gf)
+            self._slab(f'enc{i}')
+        g.add('mdt_patch_embed_bwd', xin.data_ptr(), None, dxe.data_ptr(), ids32.data_ptr() if ids32 is not None else None,
+              2 * T, Gf('model.x_embedder.proj.weight'), Gf('model.x_embedder.proj.bias'), B, sp.C, sp.R, sp.patch, L, D)
+        # ---- conditioning path backward ------------------------------------------------------
+        dmod16 = self.b16('dmod16', Bp, NM)
+        dsc = self.f32('dsc', Bp, D)
+        dc16 = self.b16('dc16', Bp, D)
+        dh1 = self.b16('dh1', Bp, D)
+        g.add('mdt_cast_f32_bf16', dmod.data_ptr(), NM, dmod16.data_ptr(), NM, B, NM, 0)
+        g.add('mdt_colsum_bf16', dmod16.data_ptr(), NM, Gp + 4 * lay.ada_b, B, NM)
+        g.add('mdt_gemm_tn', C.byref(self._k(_tn(dmod16.data_ptr(), NM, sc16.data_ptr(), D, Bp, NM, D, Gp + 4 * lay.ada_w, D))))
+        self._slab('ada')
+        g.add('mdt_gemm_nt', C.byref(self._k(_nt(dmod16.data_ptr(), NM, WT('ada'), NM, B, D, NM, epi=EPI_F32,
+                                               outf=dsc.data_ptr(), ldof=D))))
+        g.add('mdt_silu_bwd', dsc.data_ptr(), c.data_ptr(), dc16.data_ptr(), B * D)
+        g.add('mdt_gemm_tn', C.byref(self._k(_tn(dc16.data_ptr(), D, lab16.data_ptr(), YPAD, Bp, D, YPAD,
+                                               Gf('model.y_embedder.embedding_table.weight'), sp.num_classes,
+                                               n1v=D, n2v=sp.num_classes))))
+        g.add('mdt_gemm_tn', C.byref(self._k(_tn(dc16.data_ptr(), D, a1.data_ptr(), D, Bp, D, D,
+                                               Gf('model.t_embedder.mlp.2.weight'), D))))
+        g.add('mdt_colsum_bf16', dc16.data_ptr(), D, Gf('model.t_embedder.mlp.2.bias'), B, D)
+        g.add('mdt_gemm_nt', C.byref(self._k(_nt(dc16.data_ptr(), D, WT('model.t_embedder.mlp.2.weight'), D, B, D, D,
+                                               epi=EPI_DSILU, out=dh1.data_ptr(), ldo=D, aux=h1.data_ptr(), ldaux=D))))
+        g.add('mdt_gemm_tn', C.byref(self._k(_tn(dh1.data_ptr(), D, temb.data_ptr(), 256, Bp, D, 256,
+                                               Gf('model.t_embedder.mlp.0.weight'), 256))))
+        g.add('mdt_colsum_bf16', dh1.data_ptr(), D, Gf('model.t_embedder.mlp.0.bias'), B, D)
+        self._slab('misc')
+
+    def _k(self, obj):
+        self.fwd.keep.append(obj)
+        return obj
+
+    def _slab(self, name):
+        eng = self.eng
+        lo, hi = eng.lay.slabs[name]
+
+        def cb():
+            if eng.grad_slab_hook is not None:
+                eng.grad_slab_hook(name, lo, hi)
+
+        self.bwd.add_callback(cb)
+
+    # ---- one DiT block ---------------------------------------------------------------------
+    def _block_fwd(self, prefix, tag, i, x_in, mod, moff, W, heads, rows, M):
+        """DiTBlock.forward (models/maskdit.py:188-192) as 7 launches."""
+        eng, lay, f = self.eng, self.eng.lay, self.fwd
+        NM = eng.sp.n_mod
+        hd = W // heads
+        B = self.B
+        s = f'{tag}{i}' if self.train else f'{tag}'  # eval: all blocks share one buffer set
+        Pp, W16p = eng.P.data_ptr(), eng.W16.data_ptr()
+        Pf = lambda n: Pp + 4 * lay.off[f'{prefix}.{n}']  # noqa: E731
+        Wp = lambda n: W16p + 2 * lay.off[f'{prefix}.{n}']  # noqa: E731
+        mp = mod.data_ptr()
+        sh1, sc1, g1, sh2, sc2, g2 = (mp + 4 * (moff + k * W) for k in range(6))
+        xn1, st1 = self.b16(f'xn1_{s}', M, W), self.f32(f'st1_{s}', M, 2)
+        qkv = self.b16(f'qkv_{s}', M, 3 * W)
+        ao, lse = self.b16(f'ao_{s}', M, W), self.f32(f'lse_{s}', B * heads * rows)
+        ya = self.b16(f'ya_{s}', M, W)
+        xmid = self.f32(f'xmid_{s}', M, W)
+        xn2, st2 = self.b16(f'xn2_{s}', M, W), self.f32(f'st2_{s}', M, 2)
+        h, a = self.b16(f'h_{s}', M, 4 * W), self.b16(f'a_{s}', M, 4 * W)
+        ym = self.b16(f'ym_{s}', M, W)
+        if self.train:
+            xout = self.f32(f'x_{tag}{i + 1}', M, W)
+        else:  # ping-pong
+            xout = self.f32(f'x_{tag}pp{(i + 1) % 2}', M, W)
+        f.add('mdt_ln_modulate_fwd', x_in.data_ptr(), sh1, sc1, NM, rows, xn1.data_ptr(), st1.data_ptr(), M, W)
+        f.add('mdt_gemm_nt', C.byref(self._k(_nt(xn1.data_ptr(), W, Wp('attn.qkv.weight'), W, M, 3 * W, W, bias=Pf('attn.qkv.bias'),
+                                               epi=EPI_BF16, out=qkv.data_ptr(), ldo=3 * W))))
+        f.add('mdt_attn_fwd', qkv.data_ptr(), ao.data_ptr(), lse.data_ptr(), B, rows, heads, hd)
+        f.add('mdt_gemm_nt', C.byref(self._k(_nt(ao.data_ptr(), W, Wp('attn.proj.weight'), W, M, W, W, bias=Pf('attn.proj.bias'),
+                                               epi=EPI_GATE_RES, out=ya.data_ptr(), ldo=W, outf=xmid.data_ptr(), ldof=W,
+                                               res=x_in.data_ptr(), ldres=W, gate=g1, gate_ld=NM, rps=rows))))
+        f.add('mdt_ln_modulate_fwd', xmid.data_ptr(), sh2, sc2, NM, rows, xn2.data_ptr(), st2.data_ptr(), M, W)
+        f.add('mdt_gemm_nt', C.byref(self._k(_nt(xn2.data_ptr(), W, Wp('mlp.fc1.weight'), W, M, 4 * W, W, bias=Pf('mlp.fc1.bias'),
+                                               epi=EPI_GELU, out=h.data_ptr(), ldo=4 * W, out2=a.data_ptr(), ldo2=4 * W))))
+        f.add('mdt_gemm_nt', C.byref(self._k(_nt(a.data_ptr(), 4 * W, Wp('mlp.fc2.weight'), 4 * W, M, W, 4 * W, bias=Pf('mlp.fc2.bias'),
+                                               epi=EPI_GATE_RES, out=ym.data_ptr(), ldo=W, outf=xout.data_ptr(), ldof=W,
+                                               res=xmid.data_ptr(), ldres=W, gate=g2, gate_ld=NM, rps=rows))))
+        return xout
+
+    def _block_bwd(self, prefix, tag, i, x_in, mod, dmod, moff, W, heads, rows, M, dx, Gf):
+        """Backward of DiTBlock: dx (fp32 residual-stream gradient) is updated in place."""
+        eng, lay, g, ws = self.eng, self.eng.lay, self.bwd, self._ws
+        NM = eng.sp.n_mod
+        hd = W // heads
+        B = self.B
+        s = f'{tag}{i}'
+        W16p, WTp = eng.W16.data_ptr(), eng.WT16.data_ptr()
+        WT = lambda n: WTp + 2 * lay.t_off[f'{prefix}.{n}']  # noqa: E731
+        Gn = lambda n: Gf(f'{prefix}.{n}')  # noqa: E731
+        mp, dp = mod.data_ptr(), dmod.data_ptr()
+        sc1, g1, sc2, g2 = mp + 4 * (moff + W), mp + 4 * (moff + 2 * W), mp + 4 * (moff + 4 * W), mp + 4 * (moff + 5 * W)
+        dsh1, dsc1, dg1, dsh2, dsc2, dg2 = (dp + 4 * (moff + k * W) for k in range(6))
+        b = self.buf
+        xn1, st1, qkv, ao, lse = b[f'xn1_{s}'], b[f'st1_{s}'], b[f'qkv_{s}'], b[f'ao_{s}'], b[f'lse_{s}']
+        ya, xmid, xn2, st2, h, a, ym = b[f'ya_{s}'], b[f'xmid_{s}'], b[f'xn2_{s}'], b[f'st2_{s}'], b[f'h_{s}'], b[f'a_{s}'], b[f'ym_{s}']
+        dys, dh, dxn, dao, dqkv, delta = (ws[k].data_ptr() for k in ('dys', 'dh', 'dxn', 'dao', 'dqkv', 'delta'))
+        dxp = dx.data_ptr()
+        K = self._k
+        # --- MLP branch: x_out = x_mid + g2 * (fc2(gelu(fc1(xn2))))
+        g.add('mdt_gate_bwd', dxp, ym.data_ptr(), g2, NM, rows, dys, dg2, NM, Gn('mlp.fc2.bias'), M, W)
+        g.add('mdt_gemm_tn', C.byref(K(_tn(dys, W, a.data_ptr(), 4 * W, M, W, 4 * W, Gn('mlp.fc2.weight'), 4 * W))))
+        g.add('mdt_gemm_nt', C.byref(K(_nt(dys, W, WT('mlp.fc2.weight'), W, M, 4 * W, W, epi=EPI_DGELU, out=dh, ldo=4 * W,
+                                         aux=h.data_ptr(), ldaux=4 * W))))
+        g.add('mdt_gemm_tn', C.byref(K(_tn(dh, 4 * W, xn2.data_ptr(), W, M, 4 * W, W, Gn('mlp.fc1.weight'), W))))
+        g.add('mdt_colsum_bf16', dh, 4 * W, Gn('mlp.fc1.bias'), M, 4 * W)
+        g.add('mdt_gemm_nt', C.byref(K(_nt(dh, 4 * W, WT('mlp.fc1.weight'), 4 * W, M, W, 4 * W, epi=EPI_BF16, out=dxn, ldo=W))))
+        g.add('mdt_ln_modulate_bwd', dxn, xmid.data_ptr(), st2.data_ptr(), sc2, NM, rows, dxp, 1, dsh2, dsc2, NM, M, W)
+        # --- attention branch: x_mid = x_in + g1 * proj(attn(qkv(xn1)))
+        g.add('mdt_gate_bwd', dxp, ya.data_ptr(), g1, NM, rows, dys, dg1, NM, Gn('attn.proj.bias'), M, W)
+        g.add('mdt_gemm_tn', C.byref(K(_tn(dys, W, ao.data_ptr(), W, M, W, W, Gn('attn.proj.weight'), W))))
+        g.add('mdt_gemm_nt', C.byref(K(_nt(dys, W, WT('attn.proj.weight'), W, M, W, W, epi=EPI_BF16, out=dao, ldo=W))))
+        g.add('mdt_attn_bwd', qkv.data_ptr(), ao.data_ptr(), dao, lse.data_ptr(), delta, dqkv, B, rows, heads, hd)
+        g.add('mdt_gemm_tn', C.byref(K(_tn(dqkv, 3 * W, xn1.data_ptr(), W, M, 3 * W, W, Gn('attn.qkv.weight'), W))))
+        g.add('mdt_colsum_bf16', dqkv, 3 * W, Gn('attn.qkv.bias'), M, 3 * W)
+        g.add('mdt_gemm_nt', C.byref(K(_nt(dqkv, 3 * W, WT('attn.qkv.weight'), 3 * W, M, W, 3 * W, epi=EPI_BF16, out=dxn, ldo=W))))
+        g.add('mdt_ln_modulate_bwd', dxn, x_in.data_ptr(), st1.data_ptr(), sc1, NM, rows, dxp, 1, dsh1, dsc1, NM, M, W)
+
+    # ---- execution ---------------------------------------------------------------------------
+    def run_forward(self):
+        if self.eng.shadows_dirty:
+            self.eng.refresh_shadows()
+        self.fwd.run(torch.cuda.current_stream().cuda_stream)
+
+    def run_backward(self):
+        self.bwd.run(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,495 @@
+"""Per-kernel parity tests (GPU): each HIP entry point called through the C ABI against a plain
+torch fp32 reference of the same op (or the CPU oracle for the EDM / masking arithmetic).
+
+Tolerances: integer / index outputs bit-exact; bf16-output kernels within bf16 rounding of an
+fp32 computation on the same bf16-rounded inputs (rel 1e-2 of the tensor scale); fp32 kernels
+1e-5 relative."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from maskdit_amd import ops
+    from maskdit_amd import _lib
+    from maskdit_amd._lib import call
+    from oracle import maskdit_oracle as O
+
+DEV = 'cuda'
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def err(a, b):
+    a, b = a.float(), b.float()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item()
+
+
+def close(a, b, tol, name=''):
+    e = err(a, b)
+    print(f'[{name}] rel-to-max err = {e:.3e} (tol {tol:.1e})')
+    assert math.isfinite(e) and e <= tol, f'{name}: {e} > {tol}'
+
+
+def sp():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (256, 256, 128), (200, 384, 1152), (1024, 1152, 4608), (16, 128, 256)])
+def test_gemm_nt_bias(M, N, K):
+    torch.manual_seed(0)
+    A = bf(torch.randn(M, K, device=DEV))
+    W = bf(torch.randn(N, K, device=DEV) / math.sqrt(K))
+    b = torch.randn(N, device=DEV)
+    ref = A.float() @ W.float().t() + b
+    out, _, _ = ops.gemm_nt(A, W, b, ops.EPI_BF16)
+    close(out, ref, 1e-2, f'gemm_nt bf16 {M}x{N}x{K}')
+    _, _, outf = ops.gemm_nt(A, W, b, ops.EPI_F32)
+    close(outf, ref, 2e-5, f'gemm_nt f32 {M}x{N}x{K}')
+
+
+def test_gemm_nt_asymmetric_identity():
+    """A = I catches a row/col swap in the C write (asymmetric B)."""
+    K = N = 128
+    A = bf(torch.eye(128, K, device=DEV))
+    W = bf((torch.arange(N, device=DEV)[:, None] * 0.5 + torch.arange(K, device=DEV)[None, :] * 0.01))
+    _, _, outf = ops.gemm_nt(A, W, None, ops.EPI_F32)
+    close(outf, W.float().t(), 1e-6, 'gemm_nt identity')
+
+
+def test_gemm_nt_epilogues():
+    torch.manual_seed(1)
+    B_, L, D, Hd = 3, 64, 256, 512
+    M = B_ * L
+    A = bf(torch.randn(M, D, device=DEV))
+    W = bf(torch.randn(Hd, D, device=DEV) / math.sqrt(D))
+    b = torch.randn(Hd, device=DEV) * 0.1
+    pre = bf(A.float() @ W.float().t() + b)
+    h, a, _ = ops.gemm_nt(A, W, b, ops.EPI_GELU)
+    close(h, pre, 1e-2, 'gelu pre')
+    close(a, F.gelu(h.float(), approximate='tanh'), 1e-2, 'gelu act')
+    h, a, _ = ops.gemm_nt(A, W, b, ops.EPI_SILU)
+    close(a, F.silu(h.float()), 1e-2, 'silu act')
+    # gate + residual
+    W2 = bf(torch.randn(D, Hd, device=DEV) / math.sqrt(Hd))
+    b2 = torch.randn(D, device=DEV) * 0.1
+    A2 = bf(torch.randn(M, Hd, device=DEV))
+    res = torch.randn(M, D, device=DEV)
+    mod = torch.randn(B_, 3 * D, device=DEV)
+    gate = mod[:, D:2 * D]
+    y, _, xo = ops.gemm_nt(A2, W2, b2, ops.EPI_GATE_RES, res=res, gate=gate, gate_ld=3 * D, rows_per_sample=L)
+    yref = A2.float() @ W2.float().t() + b2
+    close(y, yref, 1e-2, 'gate_res y')
+    xref = res + gate.repeat_interleave(L, 0) * y.float()
+    close(xo, xref, 1e-5, 'gate_res x')
+    # dgelu / dsilu
+    aux = bf(torch.randn(M, Hd, device=DEV))
+    dA = bf(torch.randn(M, D, device=DEV))
+    Wt = bf(torch.randn(Hd, D, device=DEV) / math.sqrt(D))
+    hh = aux.float().requires_grad_(True)
+    F.gelu(hh, approximate='tanh').backward(dA.float() @ Wt.float().t())
+    o, _, _ = ops.gemm_nt(dA, Wt, None, ops.EPI_DGELU, aux=aux)
+    close(o, hh.grad, 1e-2, 'dgelu')
+    hh = aux.float().requires_grad_(True)
+    F.silu(hh).backward(dA.float() @ Wt.float().t())
+    o, _, _ = ops.gemm_nt(dA, Wt, None, ops.EPI_DSILU, aux=aux)
+    close(o, hh.grad, 1e-2, 'dsilu')
+
+
+@pytest.mark.parametrize('M,N1,N2,splits', [(64, 128, 128, 1), (256, 256, 128, 0), (1024, 384, 1152, 4), (8192, 512, 256, 0)])
+def test_gemm_tn(M, N1, N2, splits):
+    torch.manual_seed(2)
+    A = bf(torch.randn(M, N1, device=DEV))
+    Bm = bf(torch.randn(M, N2, device=DEV))
+    Cc = torch.ones(N1, N2, device=DEV)
+    ops.gemm_tn(A, Bm, Cc, splits=splits)
+    ref = A.float().t() @ Bm.float() + 1.0
+    close(Cc, ref, 1e-5, f'gemm_tn {M}x{N1}x{N2}')
+
+
+def test_gemm_tn_asymmetric_and_edges():
+    M = 64
+    A = torch.zeros(M, 128, device=DEV)
+    A[torch.arange(64), torch.arange(64)] = 1.0  # A^T picks rows of B
+    Bm = (torch.arange(M, device=DEV)[:, None] * 1.0 + torch.arange(1024, device=DEV)[None, :] * 0.001)
+    Cc = torch.zeros(128, 1000, device=DEV)
+    ops.gemm_tn(bf(A), bf(Bm), Cc, n1_valid=128, n2_valid=1000, N1=128, N2=1024)
+    ref = bf(A).float().t() @ bf(Bm).float()
+    close(Cc, ref[:, :1000], 1e-6, 'gemm_tn identity / n2 edge')
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('B_,L,H,hd', [(2, 128, 3, 72), (2, 256, 4, 32), (1, 128, 2, 64), (1, 64, 1, 80), (1, 512, 2, 72)])
+def test_attention_fwd_bwd(B_, L, H, hd):
+    torch.manual_seed(3)
+    D = H * hd
+    qkv = bf(torch.randn(B_ * L, 3 * D, device=DEV))
+    dout = bf(torch.randn(B_ * L, D, device=DEV))
+    q32 = qkv.float().reshape(B_, L, 3, H, hd).permute(2, 0, 3, 1, 4).contiguous().requires_grad_(True)
+    o_ref = F.scaled_dot_product_attention(q32[0], q32[1], q32[2])
+    o_ref2 = o_ref.transpose(1, 2).reshape(B_ * L, D)
+    out, lse = ops.attn_fwd(qkv, B_, L, H, hd)
+    close(out, o_ref2, 1e-2, f'attn fwd L{L} hd{hd}')
+    # lse (log2 domain) check
+    s = (q32[0] @ q32[1].transpose(-1, -2)) * hd ** -0.5
+    lse_ref = torch.logsumexp(s, -1) * math.log2(math.e)
+    close(lse.reshape(B_, H, L), lse_ref, 1e-3, 'attn lse')
+    o_ref2.backward(dout.float())
+    dq_ref = q32.grad.permute(1, 3, 0, 2, 4).reshape(B_ * L, 3 * D)
+    dqkv = ops.attn_bwd(qkv, out, dout, lse, B_, L, H, hd)
+    close(dqkv[:, :D], dq_ref[:, :D], 2e-2, 'attn dq')
+    close(dqkv[:, D:2 * D], dq_ref[:, D:2 * D], 2e-2, 'attn dk')
+    close(dqkv[:, 2 * D:], dq_ref[:, 2 * D:], 2e-2, 'attn dv')
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('B_,L,D', [(3, 128, 1152), (2, 64, 512), (5, 16, 384)])
+def test_ln_modulate_fwd_bwd(B_, L, D):
+    torch.manual_seed(4)
+    M = B_ * L
+    x = (torch.randn(M, D, device=DEV) * 2 + 0.5).requires_grad_(True)
+    mod = (torch.randn(B_, 3 * D, device=DEV) * 0.5).requires_grad_(True)
+    shift, scale = mod[:, :D], mod[:, 2 * D:]
+    ref = F.layer_norm(x, (D,), eps=1e-6).reshape(B_, L, D) * (1 + scale[:, None]) + shift[:, None]
+    ref = ref.reshape(M, D)
+    xn, stats = ops.ln_modulate_fwd(x.detach(), mod.detach()[:, :D], mod.detach()[:, 2 * D:], 3 * D, L)
+    close(xn, ref, 1e-2, 'ln_mod fwd')
+    dxn = bf(torch.randn(M, D, device=DEV))
+    ref.backward(dxn.float())
+    dx = torch.ones(M, D, device=DEV)
+    dmod = torch.zeros(B_, 3 * D, device=DEV)
+    ops.ln_modulate_bwd(dxn, x.detach(), stats, mod.detach()[:, 2 * D:], 3 * D, L, dx, True, dmod[:, :D], dmod[:, 2 * D:], 3 * D)
+    close(dx - 1.0, x.grad, 1e-4, 'ln_mod dx (accumulate)')
+    close(dmod[:, :D], mod.grad[:, :D], 1e-4, 'ln_mod dshift')
+    close(dmod[:, 2 * D:], mod.grad[:, 2 * D:], 1e-4, 'ln_mod dscale')
+    dx2 = torch.full((M, D), 7.0, device=DEV)
+    dmod.zero_()
+    ops.ln_modulate_bwd(dxn, x.detach(), stats, mod.detach()[:, 2 * D:], 3 * D, L, dx2, False, dmod[:, :D], dmod[:, 2 * D:], 3 * D)
+    close(dx2, x.grad, 1e-4, 'ln_mod dx (overwrite)')
+
+
+def test_gate_bwd_and_colsum():
+    torch.manual_seed(5)
+    B_, L, D = 3, 128, 1152
+    M = B_ * L
+    dx = torch.randn(M, D, device=DEV)
+    y = bf(torch.randn(M, D, device=DEV))
+    mod = torch.randn(B_, 2 * D, device=DEV)
+    gate = mod[:, D:]
+    dmod = torch.zeros(B_, 2 * D, device=DEV)
+    dbias = torch.zeros(D, device=DEV)
+    dys = ops.gate_bwd(dx, y, gate, 2 * D, L, dmod[:, D:], 2 * D, dbias)
+    ref_dys = dx * gate.repeat_interleave(L, 0)
+    close(dys, ref_dys, 1e-2, 'gate dys')
+    close(dmod[:, D:], (dx * y.float()).reshape(B_, L, D).sum(1), 1e-4, 'gate dgate')
+    close(dbias, dys.float().sum(0), 1e-4, 'gate dbias')
+    assert float(dmod[:, :D].abs().max()) == 0.0
+    out = torch.zeros(D, device=DEV)
+    ops.colsum_bf16(dys, out)
+    close(out, dys.float().sum(0), 1e-4, 'colsum')
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('B_,T,ratio', [(16, 256, 0.5), (4, 1024, 0.5), (3, 256, 0.75), (2, 64, 0.5)])
+def test_mask_sort_bit_exact(B_, T, ratio):
+    torch.manual_seed(6)
+    noise = torch.rand(B_, T, device=DEV)
+    noise[0, 5] = noise[0, 9]  # force a tie: stable rule (lower index first)
+    L = int(T * (1 - ratio))
+    ids_shuffle, ids_restore, mask, ids32 = ops.mask_sort(noise, L)
+    md = O.get_mask_from_noise(noise.cpu().numpy(), ratio)
+    assert (ids_shuffle.cpu().numpy() == md['ids_shuffle']).all()
+    assert (ids_restore.cpu().numpy() == md['ids_restore']).all()
+    assert (mask.cpu().numpy() == md['mask']).all()
+    assert (ids32[:, :T].cpu().numpy() == md['ids_shuffle']).all()
+    assert (ids32[:, T:].cpu().numpy() == md['ids_restore']).all()
+
+
+def test_mask_sort_golden(golden_dir):
+    import os
+    g = np.load(os.path.join(golden_dir, 'mask.npz'))
+    for tag in ['t256', 't1024', 't256_r75']:
+        noise = torch.from_numpy(g[f'{tag}_noise']).to(DEV)
+        T = noise.shape[1]
+        L = int(T * (1 - float(g[f'{tag}_ratio'])))
+        ids_shuffle, ids_restore, mask, _ = ops.mask_sort(noise, L)
+        s = np.sort(g[f'{tag}_noise'], axis=1)
+        ok = (np.diff(s, axis=1) != 0).all(axis=1)
+        assert (ids_shuffle[:, :L].cpu().numpy()[ok] == g[f'{tag}_ids_keep'][ok]).all()
+        assert (ids_restore.cpu().numpy()[ok] == g[f'{tag}_ids_restore'][ok]).all()
+        assert (mask.cpu().numpy()[ok] == g[f'{tag}_mask'][ok]).all()
+
+
+# ------------------------------------------------------------------------------------------
+def test_patch_embed_fwd_bwd():
+    torch.manual_seed(7)
+    B_, C_, R, p_, D = 3, 4, 32, 2, 384
+    T = (R // p_) ** 2
+    L = T // 2
+    x = torch.randn(B_, C_, R, R, device=DEV)
+    W = (torch.randn(D, C_, p_, p_, device=DEV) * 0.2).requires_grad_(True)
+    b = (torch.randn(D, device=DEV) * 0.1).requires_grad_(True)
+    pos = torch.randn(T, D, device=DEV)
+    noise = torch.rand(B_, T, device=DEV)
+    ids_shuffle, ids_restore, mask, ids32 = ops.mask_sort(noise, L)
+    tok = F.conv2d(x, W, b, stride=p_).flatten(2).transpose(1, 2) + pos[None]
+    ref = torch.gather(tok, 1, ids_shuffle[:, :L, None].expand(-1, -1, D))
+    out = torch.empty(B_, L, D, device=DEV)
+    call('mdt_patch_embed_fwd', x.data_ptr(), None, W.data_ptr(), b.data_ptr(), pos.data_ptr(), ids32.data_ptr(),
+         2 * T, out.data_ptr(), B_, C_, R, p_, L, D, sp())
+    close(out, ref, 1e-5, 'patch_embed fwd (gather)')
+    out2 = torch.empty(B_, T, D, device=DEV)
+    call('mdt_patch_embed_fwd', x.data_ptr(), None, W.data_ptr(), b.data_ptr(), pos.data_ptr(), None, 0,
+         out2.data_ptr(), B_, C_, R, p_, T, D, sp())
+    close(out2, tok, 1e-5, 'patch_embed fwd (full)')
+    dout = torch.randn(B_, L, D, device=DEV)
+    ref.backward(dout)
+    dW = torch.zeros_like(W)
+    db = torch.zeros_like(b)
+    call('mdt_patch_embed_bwd', x.data_ptr(), None, dout.data_ptr(), ids32.data_ptr(), 2 * T, dW.data_ptr(),
+         db.data_ptr(), B_, C_, R, p_, L, D, sp())
+    close(dW, W.grad, 1e-4, 'patch_embed dW')
+    close(db, b.grad, 1e-4, 'patch_embed db')
+
+
+def test_unmask_fwd_bwd():
+    torch.manual_seed(8)
+    B_, T, Dd = 3, 256, 512
+    L = T // 2
+    noise = torch.rand(B_, T, device=DEV)
+    ids_shuffle, ids_restore, mask, ids32 = ops.mask_sort(noise, L)
+    xdec = bf(torch.randn(B_, L, Dd, device=DEV))
+    mt = torch.randn(Dd, device=DEV).requires_grad_(True)
+    pos = torch.randn(T, Dd, device=DEV)
+    x32 = xdec.float().requires_grad_(True)
+    full = torch.cat([x32, mt[None, None].expand(B_, T - L, -1)], 1)
+    ref = torch.gather(full, 1, ids_restore[:, :, None].expand(-1, -1, Dd)) + pos[None]
+    out = torch.empty(B_, T, Dd, device=DEV)
+    restore32 = ids32[:, T:]
+    call('mdt_unmask_fwd', xdec.data_ptr(), restore32.data_ptr(), 2 * T, mt.data_ptr(), pos.data_ptr(), out.data_ptr(),
+         B_, T, L, Dd, sp())
+    close(out, ref, 1e-6, 'unmask fwd')
+    dout = torch.randn(B_, T, Dd, device=DEV)
+    ref.backward(dout)
+    dxdec = torch.empty(B_, L, Dd, device=DEV, dtype=torch.bfloat16)
+    dmt = torch.zeros(Dd, device=DEV)
+    call('mdt_unmask_bwd', dout.data_ptr(), ids32.data_ptr(), 2 * T, dxdec.data_ptr(), dmt.data_ptr(), B_, T, L, Dd, sp())
+    close(dxdec, x32.grad, 1e-2, 'unmask dxdec')
+    close(dmt, mt.grad, 1e-4, 'unmask dmask_token')
+
+
+def test_final_fwd_bwd():
+    torch.manual_seed(9)
+    B_, T, Dd, C_, p_ = 3, 256, 512, 4, 2
+    R = 32
+    x = (torch.randn(B_ * T, Dd, device=DEV) + 0.3).requires_grad_(True)
+    mod = (torch.randn(B_, 2 * Dd, device=DEV) * 0.3).requires_grad_(True)
+    W = (torch.randn(16, Dd, device=DEV) * 0.05).requires_grad_(True)
+    b = (torch.randn(16, device=DEV) * 0.1).requires_grad_(True)
+    xn = F.layer_norm(x, (Dd,), eps=1e-6).reshape(B_, T, Dd) * (1 + mod[:, None, Dd:]) + mod[:, None, :Dd]
+    tok = F.linear(xn, W, b)
+    ref = O.unpatchify(tok, p_, C_)
+    Fo = torch.empty(B_, C_, R, R, device=DEV)
+    stats = torch.empty(B_ * T, 2, device=DEV)
+    md = mod.detach()
+    call('mdt_final_fwd', x.data_ptr(), md.data_ptr(), md[:, Dd:].data_ptr(), 2 * Dd, W.data_ptr(), b.data_ptr(),
+         Fo.data_ptr(), stats.data_ptr(), B_, T, Dd, C_, p_, sp())
+    close(Fo, ref, 1e-5, 'final fwd')
+    dF = torch.randn(B_, C_, R, R, device=DEV)
+    ref.backward(dF)
+    dx = torch.empty(B_ * T, Dd, device=DEV)
+    dW = torch.zeros_like(W)
+    db = torch.zeros_like(b)
+    dmod = torch.zeros_like(md)
+    call('mdt_final_bwd', dF.data_ptr(), x.data_ptr(), stats.data_ptr(), md.data_ptr(), md[:, Dd:].data_ptr(), 2 * Dd,
+         W.data_ptr(), dx.data_ptr(), dW.data_ptr(), db.data_ptr(), dmod.data_ptr(), dmod[:, Dd:].data_ptr(), 2 * Dd,
+         B_, T, Dd, C_, p_, sp())
+    close(dx, x.grad, 1e-4, 'final dx')
+    close(dW, W.grad, 1e-4, 'final dW')
+    close(db, b.grad, 1e-4, 'final db')
+    close(dmod, mod.grad, 1e-4, 'final dmod')
+
+
+def test_small_elementwise():
+    torch.manual_seed(10)
+    t = torch.randn(5, device=DEV) * 2
+    out = torch.zeros(5, 256, device=DEV, dtype=torch.bfloat16)
+    call('mdt_timestep_embed', t.data_ptr(), out.data_ptr(), 256, 5, 256, sp())
+    close(out, O.timestep_embedding(t.cpu()).to(DEV), 1e-2, 'timestep_embed')
+    x = torch.randn(7, 1000, device=DEV)
+    o = torch.zeros(7, 1024, device=DEV, dtype=torch.bfloat16)
+    call('mdt_cast_f32_bf16', x.data_ptr(), 1000, o.data_ptr(), 1024, 7, 1000, 1, sp())
+    close(o[:, :1000], F.silu(x), 1e-2, 'cast+silu')
+    assert float(o[:, 1000:].abs().max()) == 0
+    dy = torch.randn(300, device=DEV)
+    xx = torch.randn(300, device=DEV).requires_grad_(True)
+    F.silu(xx).backward(dy)
+    dx = torch.empty(300, device=DEV, dtype=torch.bfloat16)
+    call('mdt_silu_bwd', dy.data_ptr(), xx.data_ptr(), dx.data_ptr(), 300, sp())
+    close(dx, xx.grad, 1e-2, 'silu_bwd')
+
+
+# ------------------------------------------------------------------------------------------
+def test_edm_prep_and_loss():
+    torch.manual_seed(11)
+    B_, C_, R, p_ = 5, 4, 32, 2
+    T = (R // p_) ** 2
+    cfg = O.make_cfg('DiT-S/2', img_resolution=R)
+    y = 0.5 * torch.randn(B_, C_, R, R)
+    rnd = torch.randn(B_, 1, 1, 1)
+    noise = torch.randn(B_, C_, R, R)
+    Fx = torch.randn(B_, C_, R, R)
+    mnoise = torch.rand(B_, T)
+    md = O.get_mask_from_noise(mnoise.numpy(), 0.5)
+    mask = torch.from_numpy(md['mask'])
+    # oracle (train_utils/loss.py restated)
+    sigma = (rnd * 1.2 - 1.2).exp()
+    weight = (sigma ** 2 + 0.25) / (sigma * 0.5) ** 2
+    yn_ref = y + noise * sigma
+    c_skip = 0.25 / (sigma ** 2 + 0.25)
+    c_out = sigma * 0.5 / (sigma ** 2 + 0.25).sqrt()
+    c_in = 1 / (0.25 + sigma ** 2).sqrt()
+    Fg = Fx.clone().requires_grad_(True)
+    D_ref = c_skip * yn_ref + c_out * Fg
+    l = weight * (D_ref - y) ** 2
+    l = F.avg_pool2d(l.mean(1), p_).flatten(1)
+    unmask = 1 - mask
+    l = (l * unmask).sum(1) / unmask.sum(1) + 0.1 * O.mae_loss(cfg, yn_ref, D_ref, mask)
+    dl = torch.randn(B_)
+    l.backward(dl)
+    # HIP
+    yd, rd, nd, Fd, md_ = y.to(DEV), rnd.flatten().to(DEV), noise.to(DEV), Fx.to(DEV), mask.to(DEV)
+    coef = torch.empty(8, B_, device=DEV)
+    yn = torch.empty_like(yd)
+    xin = torch.empty_like(yd)
+    call('mdt_edm_prep', yd.data_ptr(), rd.data_ptr(), nd.data_ptr(), coef.data_ptr(), yn.data_ptr(), xin.data_ptr(),
+         B_, C_ * R * R, -1.2, 1.2, 0.5, sp())
+    close(yn.cpu(), yn_ref, 1e-6, 'edm yn')
+    close(xin.cpu(), c_in * yn_ref, 1e-6, 'edm xin')
+    close(coef[3].cpu(), (sigma.log() / 4).flatten(), 1e-6, 'edm c_noise')
+    Dd_ = torch.empty_like(yd)
+    loss = torch.empty(B_, device=DEV)
+    call('mdt_edm_loss_fwd', Fd.data_ptr(), yn.data_ptr(), yd.data_ptr(), coef.data_ptr(), md_.data_ptr(), 0.1,
+         Dd_.data_ptr(), loss.data_ptr(), B_, C_, R, p_, sp())
+    close(Dd_.cpu(), D_ref.detach(), 1e-6, 'edm D')
+    close(loss.cpu(), l.detach(), 1e-5, 'edm loss')
+    dF = torch.empty_like(yd)
+    call('mdt_edm_loss_bwd', dl.to(DEV).data_ptr(), Dd_.data_ptr(), yn.data_ptr(), yd.data_ptr(), coef.data_ptr(),
+         md_.data_ptr(), 0.1, dF.data_ptr(), B_, C_, R, p_, sp())
+    close(dF.cpu(), Fg.grad, 1e-5, 'edm dF')
+    # no-mask path: plain mean (loss.py:54)
+    call('mdt_edm_loss_fwd', Fd.data_ptr(), yn.data_ptr(), yd.data_ptr(), coef.data_ptr(), None, 0.0,
+         Dd_.data_ptr(), loss.data_ptr(), B_, C_, R, p_, sp())
+    l2 = (weight * (D_ref.detach() - y) ** 2).mean(dim=[1, 2, 3])
+    close(loss.cpu(), l2, 1e-5, 'edm loss (no mask)')
+
+
+def test_adamw_ema_and_transpose():
+    torch.manual_seed(12)
+    n = 100003
+    p0, g = torch.randn(n), torch.randn(n) * 0.1
+    m0, v0 = torch.randn(n) * 0.01, torch.rand(n) * 0.01
+    e0 = torch.randn(n)
+    pr, mr, vr, er = p0.clone(), m0.clone(), v0.clone(), e0.clone()
+    O.adamw_step(pr, g * 0.5, mr, vr, step=3, lr=1e-3, weight_decay=0.01)
+    O.ema_update(er, pr, 0.999)
+    npad = (n + 7) // 8 * 8
+    def dev(t):
+        o = torch.zeros(npad, device=DEV)
+        o[:n] = t
+        return o
+    p_, g_, m_, v_, e_ = dev(p0), dev(g), dev(m0), dev(v0), dev(e0)
+    w16 = torch.zeros(npad, device=DEV, dtype=torch.bfloat16)
+    bc1, bc2 = 1 - 0.9 ** 3, 1 - 0.999 ** 3
+    call('mdt_adamw_ema_step', p_.data_ptr(), g_.data_ptr(), m_.data_ptr(), v_.data_ptr(), e_.data_ptr(), w16.data_ptr(),
+         n, 1e-3, 0.9, 0.999, 1e-8, 0.01, bc1, bc2, 0.999, 0.5, sp())
+    close(p_[:n].cpu(), pr, 1e-6, 'adamw p')
+    close(m_[:n].cpu(), mr, 1e-6, 'adamw m')
+    close(v_[:n].cpu(), vr, 1e-6, 'adamw v')
+    close(e_[:n].cpu(), er, 1e-6, 'ema')
+    close(w16[:n].cpu(), pr, 1e-2, 'bf16 shadow')
+    # batched transposes
+    shapes = [(384, 1152), (100, 70), (64, 64)]
+    src = torch.randn(sum(r * c for r, c in shapes), device=DEV).to(torch.bfloat16)
+    dst = torch.zeros_like(src)
+    table, off, tiles = [], 0, 0
+    for r, c in shapes:
+        table += [off, off, r, c, tiles]
+        tiles += ((r + 63) // 64) * ((c + 63) // 64)
+        off += r * c
+    tab = torch.tensor(table, dtype=torch.int64, device=DEV)
+    call('mdt_transpose_bf16_batched', src.data_ptr(), dst.data_ptr(), tab.data_ptr(), len(shapes), tiles, sp())
+    off = 0
+    for r, c in shapes:
+        assert torch.equal(dst[off:off + r * c].reshape(c, r), src[off:off + r * c].reshape(r, c).t())
+        off += r * c
+
+
+def test_sampler_kernels():
+    torch.manual_seed(13)
+    B_, chw = 3, 4 * 32 * 32
+    n = B_ * chw
+    t_steps = O.edm_t_steps(6).to(DEV)
+    step = torch.tensor([2], dtype=torch.int32, device=DEV)
+    x = torch.randn(B_, chw, dtype=torch.float64, device=DEV) * 10
+    Fc = torch.randn(2 * B_, chw, device=DEV)
+    xin = torch.empty(2 * B_, chw, device=DEV)
+    sig = torch.empty(2 * B_, device=DEV)
+    call('mdt_sampler_prep', x.data_ptr(), t_steps.data_ptr(), step.data_ptr(), 0, xin.data_ptr(), sig.data_ptr(), B_, chw,
+         2, 0.5, sp())
+    t_hat, t_next = t_steps[2], t_steps[3]
+    c_in = 1 / (0.25 + t_hat.float() ** 2).sqrt()
+    close(xin[:B_], c_in * x.float(), 1e-6, 'sampler prep')
+    assert torch.equal(xin[:B_], xin[B_:]) and torch.allclose(sig, t_hat.float().expand(2 * B_))
+    s = 1.5
+    Fg = Fc[B_:] + s * (Fc[:B_] - Fc[B_:])
+    sg = t_hat.float()
+    den = ((0.25 / (sg ** 2 + 0.25)) * x.float() + (sg * 0.5 / (sg ** 2 + 0.25).sqrt()) * Fg).double()
+    d_ref = (x - den) / t_hat
+    xn_ref = x + (t_next - t_hat) * d_ref
+    xn = torch.empty_like(x)
+    dc = torch.empty_like(x)
+    call('mdt_sampler_euler', x.data_ptr(), Fc.data_ptr(), t_steps.data_ptr(), step.data_ptr(), s, 1, xn.data_ptr(),
+         dc.data_ptr(), B_, chw, 0.5, sp())
+    close(xn, xn_ref, 1e-6, 'sampler euler')
+    F2 = torch.randn(2 * B_, chw, device=DEV)
+    Fg2 = F2[B_:] + s * (F2[:B_] - F2[B_:])
+    sg = t_next.float()
+    den2 = ((0.25 / (sg ** 2 + 0.25)) * xn_ref.float() + (sg * 0.5 / (sg ** 2 + 0.25).sqrt()) * Fg2).double()
+    dp = (xn_ref - den2) / t_next
+    ref2 = x + (t_next - t_hat) * (0.5 * d_ref + 0.5 * dp)
+    call('mdt_sampler_heun', x.data_ptr(), xn.data_ptr(), F2.data_ptr(), dc.data_ptr(), t_steps.data_ptr(), step.data_ptr(),
+         s, 1, B_, chw, 0.5, sp())
+    close(xn, ref2, 1e-6, 'sampler heun')
+    call('mdt_sampler_advance', step.data_ptr(), sp())
+    assert int(step.item()) == 3
+
+
+def test_graph_capture_replay():
+    """hipGraph helpers: capture two launches on a side stream, replay twice."""
+    import ctypes as C
+    L = _lib.lib()
+    a = torch.ones(1024, device=DEV)
+    b = torch.full((1024,), 2.0, device=DEV)
+    o = torch.zeros(1024, device=DEV)
+    s = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        st = s.cuda_stream
+        _lib.check(L.mdt_graph_begin(st), 'begin')
+        call('mdt_add_f32', a.data_ptr(), b.data_ptr(), o.data_ptr(), 1024, st)
+        call('mdt_add_f32', o.data_ptr(), b.data_ptr(), a.data_ptr(), 1024, st)
+        g = C.c_void_p()
+        _lib.check(L.mdt_graph_end(st, C.byref(g)), 'end')
+        _lib.check(L.mdt_graph_launch(g, st), 'launch')
+        _lib.check(L.mdt_graph_launch(g, st), 'launch')
+    s.synchronize()
+    assert float(a[0]) == 9.0 and float(o[0]) == 7.0
+    _lib.check(L.mdt_graph_destroy(g), 'destroy')
