@@ -1,0 +1,288 @@
+#!/usr/bin/env python
+"""bench.py -- MaskDiT-XL/2 training-step throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]            # N = 1: plain process
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # N > 1 (driver)
+
+One "step" = one optimizer step of the reference's training loop body (train.py:200-230) on
+the workload BASELINE.json quotes the metric on (configs[1]): MaskDiT-XL/2, ImageNet-256
+latents [B,4,32,32], mask_ratio 0.5, mae_loss_coef 0.1, class-dropout 0.1, bf16 GEMM/attention
+compute with fp32 master weights, GLOBAL batch 1024 -- as `accum` micro-batches per GPU --
+forward + backward + DP gradient all-reduce + fused AdamW + EMA.  Synthetic latents / labels
+are resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
+
+Extra objects in the line:
+  roofline     : the dominant kernel (gemm_nt_kernel, bf16 MFMA): algorithmic FLOPs of its
+                 launches / their summed duration, both measured live with HIP events recorded
+                 on the launch stream around every gemm_nt launch of the timed steps.
+  cpu_baseline : the CPU oracle (oracle/maskdit_oracle.py, a restatement of the reference
+                 path pinned to reference-generated fixtures) timed on this host's cores on a
+                 bounded sample (XL/2, batch 16, fwd+bwd+AdamW+EMA), rank 0, N = 1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--model', default='DiT-XL/2')
+    ap.add_argument('--resolution', type=int, default=32, help='latent resolution (32 = ImageNet-256, 64 = ImageNet-512)')
+    ap.add_argument('--global-batch', type=int, default=1024)
+    ap.add_argument('--micro-batch', type=int, default=256, help='samples per forward/backward pass per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-events', action='store_true', help='skip the per-launch HIP events (roofline = null)')
+    ap.add_argument('--cpu-batch', type=int, default=16)
+    return ap.parse_args()
+
+
+class GemmTimer:
+    """HIP events around every gemm_nt launch of a plan (recorded on the launch stream)."""
+
+    def __init__(self, lib):
+        self.lib = lib
+        self.pool = []
+        self.used = 0
+        self.records = []  # (start, stop, flops)
+
+    def _ev(self):
+        if self.used == len(self.pool):
+            e = C.c_void_p()
+            self.lib.mdt_event_create(C.byref(e))
+            self.pool.append(e)
+        e = self.pool[self.used]
+        self.used += 1
+        return e
+
+    def wrap(self, plan):
+        """Replace plan.run by an instrumented replay."""
+        from maskdit_amd import _lib
+        timer = self
+        calls = plan.calls
+
+        def run(stream):
+            for fn, args, name in calls:
+                if fn is None:
+                    args()
+                    continue
+                if name == 'mdt_gemm_nt':
+                    a = args[0]._obj
+                    s, e = timer._ev(), timer._ev()
+                    timer.lib.mdt_event_record(s, stream)
+                    rc = fn(*args, stream)
+                    timer.lib.mdt_event_record(e, stream)
+                    timer.records.append((s, e, 2.0 * a.M * a.N * a.K))
+                else:
+                    rc = fn(*args, stream)
+                if rc != 0:
+                    raise _lib.MaskDiTLibError(f'{name} failed ({rc}): {_lib.lib().mdt_last_error().decode()}')
+
+        plan.run = run
+
+    def summarise(self):
+        ms = C.c_float()
+        tot_ms, tot_fl = 0.0, 0.0
+        for s, e, fl in self.records:
+            self.lib.mdt_event_elapsed_ms(s, e, C.byref(ms))
+            tot_ms += ms.value
+            tot_fl += fl
+        n = len(self.records)
+        return n, tot_ms, tot_fl
+
+
+def cpu_baseline(batch, model, R):
+    """Oracle train step (fwd + bwd + AdamW + EMA) on the host cores; bounded sample."""
+    from oracle import maskdit_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.make_cfg(model, img_resolution=R)
+    P = O.init_params(cfg, seed=0, dezero=True)
+    names = [k for k in P if k not in O.NON_TRAINABLE]
+    Mm = {k: torch.zeros_like(P[k]) for k in names}
+    V = {k: torch.zeros_like(P[k]) for k in names}
+    EMA = {k: P[k].clone() for k in names}
+    g = torch.Generator().manual_seed(0)
+    T = (R // cfg['patch']) ** 2
+    times = []
+    for it in range(3):
+        images = 0.5 * torch.randn(batch, 4, R, R, generator=g)
+        labels = torch.zeros(batch, 1000)
+        labels[torch.arange(batch), torch.randint(0, 1000, (batch,), generator=g)] = 1
+        labels *= (torch.rand(batch, 1, generator=g) >= 0.1).float()
+        rnd, noise = torch.randn(batch, 1, 1, 1, generator=g), torch.randn(batch, 4, R, R, generator=g)
+        mnoise = torch.rand(batch, T, generator=g)
+        t0 = time.perf_counter()
+        O.train_step(P, Mm, V, EMA, cfg, images, labels, rnd, noise, mnoise, 0.5, 0.1, step=it + 1)
+        times.append(time.perf_counter() - t0)
+    best = min(times[1:])
+    return {'value': round(batch / best, 3), 'unit': 'img/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{model} latent {R}x{R}, batch {batch}, mask 0.5, fp32 CPU oracle train step '
+                      f'(fwd+bwd+AdamW+EMA), 1 warm-up + 2 timed, best of 2 ({best:.2f} s/step)'}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)')
+        args.gpus = world
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+
+    import maskdit_amd as M
+    from maskdit_amd import _lib
+    lib = _lib.lib()
+
+    R = args.resolution
+    per_gpu = args.global_batch // world
+    assert per_gpu * world == args.global_batch, 'global batch must divide by the number of GPUs'
+    mb = min(args.micro_batch, per_gpu)
+    accum = per_gpu // mb
+    assert accum * mb == per_gpu
+
+    torch.manual_seed(0)  # train.py:67-68: same seed on every rank
+    net = M.Precond_models['edm'](img_resolution=R, img_channels=4, num_classes=1000, model_type=args.model,
+                                  use_decoder=True, mae_loss_coef=0.1, pad_cls_token=False)
+    # the reference zero-initialises every adaLN / output projection; re-draw them so that no GEMM
+    # sees an all-zero operand (zero operands clock ~20 % higher and would flatter the number)
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.requires_grad and float(p.abs().max()) == 0.0:
+                p.normal_(std=0.02)
+    net = net.to(dev).train()
+    import copy
+    ema = copy.deepcopy(net).eval()
+    for p in ema.parameters():
+        p.requires_grad_(False)
+    opt = M.FusedAdam(net.parameters(), lr=1e-4, adam_w_mode=True, weight_decay=0)
+    opt.fuse_ema(ema, 0.9999)
+    model = M.DataParallel(net) if world > 1 else net
+    loss_fn = M.Losses['edm']()
+
+    # synthetic data of the dataset's shape, resident in HBM: latents with std = sigma_data,
+    # one-hot labels with class-dropout 0.1 applied (train.py:208-209)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x_all = 0.5 * torch.randn(per_gpu, 4, R, R, device=dev, generator=gen)
+    cls = torch.randint(0, 1000, (per_gpu,), device=dev, generator=gen)
+    y_all = torch.zeros(per_gpu, 1000, device=dev)
+    y_all[torch.arange(per_gpu, device=dev), cls] = 1
+    y_all *= (torch.rand(per_gpu, 1, device=dev, generator=gen) >= 0.1).float()
+    loss_acc = torch.zeros((), device=dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        for a in range(accum):
+            xs, ys = x_all[a * mb:(a + 1) * mb], y_all[a * mb:(a + 1) * mb]
+            last = a == accum - 1
+            if world > 1 and not last:
+                with model.no_sync():
+                    loss = loss_fn(model, xs, ys, mask_ratio=0.5, mae_loss_coef=0.1)
+                    (loss.mean() / accum).backward()
+            else:
+                loss = loss_fn(model, xs, ys, mask_ratio=0.5, mae_loss_coef=0.1)
+                (loss.mean() / accum).backward()
+            loss_acc.add_(loss.detach().mean() / accum)
+        if world > 1:
+            model.finish_grad_sync()
+        opt.step()
+        M.update_ema(ema, net, 0.9999)  # folded into opt.step() (fuse_ema): no extra pass
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    timer = None
+    if not args.no_kernel_events:
+        timer = GemmTimer(lib)
+        pl = net.engine().plan(mb, True, True, None)
+        timer.wrap(pl.fwd)
+        timer.wrap(pl.bwd)
+    loss_acc.zero_()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    mean_loss = float(loss_acc.item()) / max(args.steps, 1)
+    if not (mean_loss == mean_loss and abs(mean_loss) < 1e6):
+        raise SystemExit(f'bench: non-finite / absurd training loss {mean_loss}')
+
+    roof = None
+    if timer is not None:
+        n, tot_ms, tot_fl = timer.summarise()
+        if n and tot_ms > 0:
+            ach = tot_fl / (tot_ms * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'kernel': 'gemm_nt_kernel', 'achieved': round(ach, 1), 'peak': MFMA_BF16_PEAK_TFLOPS,
+                    'unit': 'TFLOP/s', 'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
+                    'launches': n, 'avg_launch_us': round(tot_ms * 1e3 / n, 2),
+                    'avg_flops_per_launch': round(tot_fl / n / 1e9, 3), 'flops_unit': 'GFLOP',
+                    'share_of_step_time': round(tot_ms * 1e-3 / dt, 4)}
+            pmc = os.path.join(ROOT, 'profiles', 'pmc_gemm_nt.json')
+            if os.path.exists(pmc):
+                try:
+                    roof['traffic'] = json.load(open(pmc)).get('hbm_bytes_per_launch')
+                except Exception:
+                    pass
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(args.cpu_batch, args.model, R)
+        except Exception as e:  # the oracle is a checker; its absence must not void the GPU number
+            cpu = {'value': None, 'error': repr(e)}
+
+    if rank == 0:
+        value = args.global_batch * args.steps / dt
+        line = {
+            'metric': 'training img/sec MaskDiT-XL/2 256 mask=0.5 bs=1024' if (args.model, R) == ('DiT-XL/2', 32)
+            else f'training img/sec {args.model} latent{R} mask=0.5 bs={args.global_batch}',
+            'value': round(value, 2), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'strong',
+            'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'{args.model} ImageNet{R * 8}-latent [{R}x{R}x4], mask_ratio=0.5, mae_loss_coef=0.1, '
+                                   f'fwd+bwd+grad-allreduce+AdamW+EMA, random-init (de-zeroed) weights',
+                       'global_batch': args.global_batch, 'per_gpu_batch': per_gpu, 'micro_batch': mb, 'accum': accum,
+                       'tokens_per_sample': (R // 2) ** 2, 'kept_tokens': (R // 2) ** 2 // 2, 'parallelism': f'dp{world}'},
+            'model_tflops_per_s': round(value * 392.7e9 / 1e12, 1) if (args.model, R) == ('DiT-XL/2', 32) else None,
+            'mean_loss': round(mean_loss, 5),
+            'roofline': roof, 'cpu_baseline': cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

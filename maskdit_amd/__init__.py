@@ -2,7 +2,21 @@
 
 Only what the hot path needs lives here: `csrc/` (hand-written HIP kernels + the C ABI of
 libmaskdit_hip.so, declared in include/maskdit_hip.h) and the host-side mirror of the
-reference's Python surface (Precond_models, Losses, edm_sampler, FusedAdam, update_ema).
-There is no non-HIP fallback: computing without libmaskdit_hip.so raises.
+reference's Python surface:
+
+    Precond_models['edm'] / EDMPrecond, DiT_models, get_mask     <- models/maskdit.py
+    Losses['edm'] / EDMLoss, unwrap_model                        <- train_utils/loss.py, helper.py
+    FusedAdam, update_ema                                        <- apex.optimizers, train_utils/helper.py
+    edm_sampler                                                  <- sample.py
+    DataParallel                                                 <- accelerate / DDP (train.py:178)
+
+There is no non-HIP fallback: computing without libmaskdit_hip.so or off-GPU raises.
 """
 __version__ = '0.1.0'
+
+from ._lib import MaskDiTLibError, build  # noqa: F401
+from .precond import DiT_models, EDMPrecond, Precond_models, get_mask  # noqa: F401
+from .loss import EDMLoss, Losses, unwrap_model  # noqa: F401
+from .optim import FusedAdam, update_ema  # noqa: F401
+from .sampler import edm_sampler  # noqa: F401
+from .ddp import DataParallel, GradSlabReducer  # noqa: F401

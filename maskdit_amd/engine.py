@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import weakref
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Tuple
 
@@ -41,6 +42,7 @@ MODEL_CONFIGS = {  # models/maskdit.py:649-715  name -> (depth, hidden, patch, h
     'DiT-S/2': (12, 384, 2, 6), 'DiT-S/4': (12, 384, 4, 6), 'DiT-S/8': (12, 384, 8, 6),
 }
 YPAD = 1024  # label one-hot width padded to a multiple of 128 for the GEMMs
+LIVE_ENGINES: 'weakref.WeakSet' = weakref.WeakSet()  # lets the optimizer map a parameter view back to its arena
 
 
 def _rup(x, m):
@@ -251,6 +253,8 @@ class Engine:
         self.shadows_dirty = True
         self._plans: Dict[tuple, 'PassPlan'] = {}
         self.grad_slab_hook: Optional[Callable[[str, int, int], None]] = None  # DP overlap (ddp.py)
+        self.ema_applied = None
+        LIVE_ENGINES.add(self)
 
     # ---- arenas ------------------------------------------------------------------------
     def view(self, arena: torch.Tensor, name: str) -> torch.Tensor:
@@ -278,6 +282,7 @@ class Engine:
 
     # ---- plans -------------------------------------------------------------------------
     def plan(self, B: int, masked: bool, train: bool, L: Optional[int] = None) -> 'PassPlan':
+        L = (L if L is not None else self.sp.T // 2) if masked else None
         key = (B, masked, train, L)
         pl = self._plans.get(key)
         if pl is None:
@@ -359,7 +364,9 @@ class PassPlan:
         f, g = self.fwd, self.bwd
         # ---------------- inputs -----------------------------------------------------------
         xin = self.f32('xin', B, sp.C, sp.R, sp.R)
-        cn = self.f32('c_noise', B)
+        coef = self.f32('coef', 8, B)  # rows: c_skip, c_out, c_in, c_noise, weight, sigma, -, -
+        cn = coef[3]
+        self.buf['c_noise'] = cn
         lab = self.f32('labels', B, sp.num_classes)
         ids32 = self.t('ids32', (B, 2 * T), torch.int32) if self.masked else None
         Fx = self.f32('F', B, sp.C, sp.R, sp.R)

@@ -1,0 +1,195 @@
+"""Drop-in for `sample.edm_sampler` (sample.py:30-66): EDM 2nd-order Heun sampler, Karras
+rho=7 schedule, fp64 state, fp32 network I/O, optional classifier-free guidance.
+
+For the shipped setting (S_churn = 0 => gamma = 0, x_hat = x_cur, t_hat = t_cur) with a
+maskdit_amd EDMPrecond, one whole Heun step -- input scaling, the CFG-doubled network
+evaluation, the EDM output blend, Euler update, second evaluation, Heun average, step-counter
+bump -- is captured ONCE into a hipGraph on a side stream; every step replays that graph,
+reading its scalars (t_i, t_{i+1}) from a device-side fp64 schedule indexed by a device-side
+counter.  The last step (no 2nd-order correction, sample.py:61) replays a second, shorter graph.
+With S_churn > 0 the generic loop below runs (network still in HIP, state algebra in torch).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call
+from .loss import unwrap_model
+from .precond import EDMPrecond
+
+
+def edm_t_steps(num_steps, sigma_min, sigma_max, rho, device) -> torch.Tensor:
+    """sample.py:40-43: fp64 schedule with t_N = 0 appended."""
+    i = torch.arange(num_steps, dtype=torch.float64, device=device)
+    t = (sigma_max ** (1 / rho) + i / (num_steps - 1) * (sigma_min ** (1 / rho) - sigma_max ** (1 / rho))) ** rho
+    return torch.cat([t, torch.zeros_like(t[:1])])
+
+
+class _GraphedHeun:
+    """Captured graphs + persistent state buffers for one (net, batch, cfg?) shape."""
+
+    def __init__(self, net: EDMPrecond, B: int, use_cfg: bool, max_steps: int = 1024):
+        self.net, self.B, self.use_cfg = net, B, use_cfg
+        sp = net.spec
+        dev = next(net.parameters()).device
+        self.chw = sp.C * sp.R * sp.R
+        self.dup = 2 if use_cfg else 1
+        self.eng = net.engine()
+        self.pl = self.eng.plan(B * self.dup, False, False, None)
+        f64 = dict(device=dev, dtype=torch.float64)
+        self.x_hat = torch.zeros(B, self.chw, **f64)
+        self.x_next = torch.zeros(B, self.chw, **f64)
+        self.d_cur = torch.zeros(B, self.chw, **f64)
+        self.t_steps = torch.zeros(max_steps + 1, **f64)
+        self.step_idx = torch.zeros(1, device=dev, dtype=torch.int32)
+        self.sig = torch.zeros(B * self.dup, device=dev, dtype=torch.float32)
+        self.cfg_scale = torch.zeros(1)  # host copy of the captured value
+        self.stream = torch.cuda.Stream(device=dev)
+        self.graph_full = self.graph_last = None
+        self.captured_cfg = None
+
+    def _eval(self, st, src, which):
+        """network evaluation at t_{i+which} of fp64 state `src` -> plan buffer F"""
+        pl, sd = self.pl, float(self.net.sigma_data)
+        call('mdt_sampler_prep', src.data_ptr(), self.t_steps.data_ptr(), self.step_idx.data_ptr(), which,
+             pl.buf['xin'].data_ptr(), self.sig.data_ptr(), self.B, self.chw, self.dup, sd, st)
+        call('mdt_precond_coef', self.sig.data_ptr(), pl.buf['coef'].data_ptr(), self.B * self.dup, sd, st)
+        pl.fwd.run(st)
+
+    def _record(self, st, cfg_scale, last):
+        sd = float(self.net.sigma_data)
+        Fp = self.pl.buf['F'].data_ptr()
+        self._eval(st, self.x_hat, 0)
+        call('mdt_sampler_euler', self.x_hat.data_ptr(), Fp, self.t_steps.data_ptr(), self.step_idx.data_ptr(), cfg_scale,
+             int(self.use_cfg), self.x_next.data_ptr(), self.d_cur.data_ptr(), self.B, self.chw, sd, st)
+        if not last:
+            self._eval(st, self.x_next, 1)
+            call('mdt_sampler_heun', self.x_hat.data_ptr(), self.x_next.data_ptr(), Fp, self.d_cur.data_ptr(),
+                 self.t_steps.data_ptr(), self.step_idx.data_ptr(), cfg_scale, int(self.use_cfg), self.B, self.chw, sd, st)
+        call('mdt_sampler_advance', self.step_idx.data_ptr(), st)
+
+    def capture(self, cfg_scale: float):
+        L = _lib.lib()
+        self.destroy()
+        if self.eng.shadows_dirty:
+            self.eng.refresh_shadows()
+        torch.cuda.synchronize()
+        graphs = []
+        with torch.cuda.stream(self.stream):
+            st = self.stream.cuda_stream
+            for last in (False, True):
+                _lib.check(L.mdt_graph_begin(st), 'mdt_graph_begin')
+                try:
+                    self._record(st, cfg_scale, last)
+                finally:
+                    g = C.c_void_p()
+                    rc = L.mdt_graph_end(st, C.byref(g))
+                _lib.check(rc, 'mdt_graph_end')
+                graphs.append(g)
+        self.graph_full, self.graph_last = graphs
+        self.captured_cfg = cfg_scale
+
+    def destroy(self):
+        L = _lib.lib()
+        for g in (self.graph_full, self.graph_last):
+            if g is not None:
+                L.mdt_graph_destroy(g)
+        self.graph_full = self.graph_last = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+_CACHE: Dict[Tuple[int, int, bool], _GraphedHeun] = {}
+
+
+def _graphed(net: EDMPrecond, B: int, use_cfg: bool) -> _GraphedHeun:
+    key = (id(net.engine()), B, use_cfg)
+    g = _CACHE.get(key)
+    if g is None or g.eng is not net.engine() or g.pl is not net.engine()._plans.get((B * g.dup, False, False, None)):
+        if len(_CACHE) >= 4:
+            _CACHE.pop(next(iter(_CACHE))).destroy()
+        g = _GraphedHeun(net, B, use_cfg)
+        _CACHE[key] = g
+    return g
+
+
+@torch.no_grad()
+def edm_sampler(net, latents, class_labels=None, cfg_scale=None, feat=None, randn_like=torch.randn_like, num_steps=18,
+                sigma_min=0.002, sigma_max=80, rho=7, S_churn=0, S_min=0, S_max=float('inf'), S_noise=1, use_graph=True):
+    """Same signature and result (fp64 [N, C, H, W]) as sample.py:30-66."""
+    raw = unwrap_model(net)
+    if not isinstance(raw, EDMPrecond):
+        raise TypeError(f'maskdit_amd.edm_sampler expects a maskdit_amd EDMPrecond, got {type(raw).__name__}')
+    if feat is not None:
+        raise NotImplementedError('feat conditioning is outside the shipped configurations')
+    if not latents.is_cuda:
+        raise _lib.MaskDiTLibError('maskdit_amd: latents are not on a HIP device; there is no CPU path')
+    if raw.training:
+        raise RuntimeError('edm_sampler needs net.eval() (generate.py:41)')
+    sigma_min = max(sigma_min, raw.sigma_min)
+    sigma_max = min(sigma_max, raw.sigma_max)
+    t_steps = edm_t_steps(num_steps, sigma_min, sigma_max, rho, latents.device)
+    B = latents.shape[0]
+    labels = raw._labels(class_labels, B, latents.device)
+    x_next = latents.to(torch.float64) * t_steps[0]  # sample.py:46
+    if S_churn != 0 or not use_graph:
+        return _generic_loop(raw, x_next, t_steps, labels, cfg_scale, randn_like, num_steps, S_churn, S_min, S_max, S_noise)
+
+    use_cfg = cfg_scale is not None
+    g = _graphed(raw, B, use_cfg)
+    if num_steps + 1 > g.t_steps.numel():
+        raise ValueError('num_steps exceeds the captured schedule capacity (1024)')
+    s = float(cfg_scale) if use_cfg else 0.0
+    if g.graph_full is None or g.captured_cfg != s or raw.engine().shadows_dirty:
+        g.capture(s)
+    L = _lib.lib()
+    cur = torch.cuda.current_stream()
+    g.t_steps[:num_steps + 1].copy_(t_steps)
+    g.step_idx.zero_()
+    g.x_hat.copy_(x_next.reshape(B, -1))
+    lab = g.pl.buf['labels']
+    lab[:B].copy_(labels)
+    if use_cfg:
+        lab[B:].zero_()  # models/maskdit.py:566-567: y_null
+    g.stream.wait_stream(cur)
+    with torch.cuda.stream(g.stream):
+        st = g.stream.cuda_stream
+        for i in range(num_steps):
+            # sample.py:53 draws randn_like(x_cur) even when gamma = 0 (its coefficient is then 0):
+            # keep the caller's generator in the same state as the reference would leave it
+            randn_like(g.x_hat.view_as(latents))
+            last = i == num_steps - 1
+            _lib.check(L.mdt_graph_launch(g.graph_last if last else g.graph_full, st), 'mdt_graph_launch')
+            if not last:
+                g.x_hat.copy_(g.x_next)  # x_cur <- x_next (sample.py:48); on the same stream, after the graph
+        out = g.x_next.clone().view_as(x_next)
+    cur.wait_stream(g.stream)
+    return out
+
+
+def _generic_loop(net, x_next, t_steps, labels, cfg_scale, randn_like, num_steps, S_churn, S_min, S_max, S_noise):
+    """sample.py:47-64 verbatim in structure (stochastic churn supported); used when the
+    graph path does not apply."""
+    for i in range(num_steps):
+        t_cur, t_next = t_steps[i], t_steps[i + 1]
+        x_cur = x_next
+        gamma = min(S_churn / num_steps, np.sqrt(2) - 1) if S_min <= t_cur <= S_max else 0
+        t_hat = net.round_sigma(t_cur + gamma * t_cur)
+        x_hat = x_cur + (t_hat ** 2 - t_cur ** 2).sqrt() * S_noise * randn_like(x_cur)
+        denoised = net(x_hat.float(), t_hat, labels, cfg_scale)['x'].to(torch.float64)
+        d_cur = (x_hat - denoised) / t_hat
+        x_next = x_hat + (t_next - t_hat) * d_cur
+        if i < num_steps - 1:
+            denoised = net(x_next.float(), t_next, labels, cfg_scale)['x'].to(torch.float64)
+            d_prime = (x_next - denoised) / t_next
+            x_next = x_hat + (t_next - t_hat) * (0.5 * d_cur + 0.5 * d_prime)
+    return x_next
