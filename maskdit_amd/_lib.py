@@ -79,6 +79,7 @@ _PLAIN = {
     'mdt_event_record': [vp, vp],
     'mdt_event_elapsed_ms': [vp, vp, C.POINTER(f32)],
     'mdt_event_destroy': [vp],
+    'mdt_set_tuning': [C.c_char_p, i32],
 }
 EXPORTED = sorted(list(_PROTOS) + list(_PLAIN) + ['mdt_last_error', 'mdt_version'])
 

@@ -21,6 +21,15 @@ int mdt_check_launch(const char* what) {
 }
 
 extern "C" const char* mdt_last_error(void) { return g_err; }
+
+static int g_tuning[MDT_TUNE_COUNT] = {0};
+int mdt_get_tuning_int(int key) { return (key >= 0 && key < MDT_TUNE_COUNT) ? g_tuning[key] : 0; }
+extern "C" int mdt_set_tuning(const char* key, int value) {
+  MDT_REQUIRE(key, "set_tuning: null key");
+  if (!strcmp(key, "gemm_nt_variant")) { g_tuning[MDT_TUNE_GEMM_NT_VARIANT] = value; return MDT_OK; }
+  mdt_set_error("set_tuning: unknown key");
+  return MDT_ERR_ARG;
+}
 extern "C" int mdt_version(void) { return 1; }
 
 #define HIP_TRY(call, what)                                                         \

@@ -15,47 +15,12 @@
 #include "common.h"
 #include "../../include/maskdit_hip.h"
 
+#include "gemm_common.h"
+
 #define BM 128
 #define BN 128
 #define BK 64
 #define STAGE_BYTES 32768  // A 16 KiB + B 16 KiB
-#define GROUP_M 8
-
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-  // blocks are dispatched round-robin over the 8 XCDs; give each XCD a contiguous id range.
-  int q = nwg >> 3, r = nwg & 7;
-  int xcd = bid & 7, idx = bid >> 3;
-  int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return base + idx;
-}
-
-__device__ __forceinline__ void tile_coords(int s, int tiles_m, int tiles_n, int& tm, int& tn) {
-  int per_group = GROUP_M * tiles_n;
-  int group = s / per_group;
-  int first_m = group * GROUP_M;
-  int gm = min(tiles_m - first_m, GROUP_M);
-  int in = s - group * per_group;
-  tm = first_m + in % gm;
-  tn = in / gm;
-}
-
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
-  __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gsrc), LDS_PTR(lds_dst), 16, 0, 0);
-}
-
-struct NTParams {
-  const bf16* A; int lda;
-  const bf16* B; int ldb;
-  int M, N, K;
-  const float* bias;
-  int epi;
-  bf16* out; int ldo;
-  bf16* out2; int ldo2;
-  float* outf; int ldof;
-  const float* res; int ldres;
-  const float* gate; int gate_ld; int rows_per_sample;
-  const bf16* aux; int ldaux;
-};
 
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
@@ -151,66 +116,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTParams p) {
       f32x4 t = *(const f32x4*)(stg + er * 68 + ec + q * 4);
       v[q * 4 + 0] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
     }
-    if (m >= p.M) continue;
-    if (p.bias) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 b = *(const f32x4*)(p.bias + n + q * 4);
-        v[q * 4 + 0] += b[0]; v[q * 4 + 1] += b[1]; v[q * 4 + 2] += b[2]; v[q * 4 + 3] += b[3];
-      }
-    }
-    const int epi = p.epi;
-    if (epi == MDT_EPI_DGELU || epi == MDT_EPI_DSILU) {
-      const bf16* ax = p.aux + (long)m * p.ldaux + n;
-      bf16x8 h0 = *(const bf16x8*)ax, h1 = *(const bf16x8*)(ax + 8);
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        float h = bf2f(q < 8 ? h0[q] : h1[q - 8]);
-        v[q] *= (epi == MDT_EPI_DGELU) ? gelu_tanh_grad(h) : silu_grad(h);
-      }
-    }
-    if (epi == MDT_EPI_F32) {
-      float* o = p.outf + (long)m * p.ldof + n;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) *(f32x4*)(o + q * 4) = (f32x4){v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]};
-    }
-    bf16x8 o0, o1;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { o0[q] = f2bf(v[q]); o1[q] = f2bf(v[q + 8]); }
-    if (p.out) {
-      bf16* o = p.out + (long)m * p.ldo + n;
-      *(bf16x8*)o = o0;
-      *(bf16x8*)(o + 8) = o1;
-    }
-    if (epi == MDT_EPI_GELU || epi == MDT_EPI_SILU) {
-      bf16x8 a0, a1;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        float h0 = bf2f(o0[q]), h1 = bf2f(o1[q]);
-        a0[q] = f2bf(epi == MDT_EPI_GELU ? gelu_tanh(h0) : silu(h0));
-        a1[q] = f2bf(epi == MDT_EPI_GELU ? gelu_tanh(h1) : silu(h1));
-      }
-      bf16* o = p.out2 + (long)m * p.ldo2 + n;
-      *(bf16x8*)o = a0;
-      *(bf16x8*)(o + 8) = a1;
-    } else if (epi == MDT_EPI_GATE_RES) {
-      const float* g = p.gate + (long)(m / p.rows_per_sample) * p.gate_ld + n;
-      const float* rs = p.res + (long)m * p.ldres + n;
-      float* o = p.outf + (long)m * p.ldof + n;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        f32x4 gv = *(const f32x4*)(g + q * 4);
-        f32x4 rv = *(const f32x4*)(rs + q * 4);
-        f32x4 ov;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          int c = q * 4 + e;
-          float y = bf2f(c < 8 ? o0[c] : o1[c - 8]);
-          ov[e] = rv[e] + gv[e] * y;
-        }
-        *(f32x4*)(o + q * 4) = ov;
-      }
-    }
+    nt_epilogue_row<16>(p, m, n, v);
   }
 }
 
@@ -355,6 +261,13 @@ extern "C" int mdt_gemm_nt(const mdt_gemm_nt_args* a, mdt_stream_t stream) {
   p.outf = a->outf; p.ldof = a->ldof; p.res = a->res; p.ldres = a->ldres;
   p.gate = a->gate; p.gate_ld = a->gate_ld; p.rows_per_sample = a->rows_per_sample;
   p.aux = (const bf16*)a->aux; p.ldaux = a->ldaux;
+  // large aligned problems: 256 x (64*NF) tile, 8-wave phase-pipelined kernel (gemm_nt8.hip)
+  const int variant = mdt_get_tuning_int(MDT_TUNE_GEMM_NT_VARIANT);
+  if (variant != 1 && a->M % 256 == 0 && a->K % 128 == 0) {
+    int nf = (a->N % 256 == 0) ? 4 : (a->N % 192 == 0) ? 3 : 2;
+    long tiles8 = (long)(a->M / 256) * (a->N / (64 * nf));
+    if (variant == 2 || tiles8 >= 192) return launch_gemm_nt8(p, nf, (hipStream_t)stream);
+  }
   int tiles = cdiv(a->M, BM) * (a->N / BN);
   hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, p);
   return mdt_check_launch("gemm_nt");

@@ -1,0 +1,126 @@
+// Shared pieces of the bf16 NT GEMM kernels (gemm.hip: 128x128 tile; gemm_nt8.hip: 256 x 64*NF
+// tile): parameter block, XCD-aware tile order, LDS-DMA helper and the fused row epilogue.
+#pragma once
+#include "common.h"
+#include "../../include/maskdit_hip.h"
+
+#define GROUP_M 8
+
+struct NTParams {
+  const bf16* A; int lda;
+  const bf16* B; int ldb;
+  int M, N, K;
+  const float* bias;
+  int epi;
+  bf16* out; int ldo;
+  bf16* out2; int ldo2;
+  float* outf; int ldof;
+  const float* res; int ldres;
+  const float* gate; int gate_ld; int rows_per_sample;
+  const bf16* aux; int ldaux;
+};
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  // blocks are dispatched round-robin over the 8 XCDs; give each XCD a contiguous id range
+  // (bijective for any nwg).
+  int q = nwg >> 3, r = nwg & 7;
+  int xcd = bid & 7, idx = bid >> 3;
+  int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+__device__ __forceinline__ void tile_coords(int s, int tiles_m, int tiles_n, int& tm, int& tn) {
+  int per_group = GROUP_M * tiles_n;
+  int group = s / per_group;
+  int first_m = group * GROUP_M;
+  int gm = min(tiles_m - first_m, GROUP_M);
+  int in = s - group * per_group;
+  tm = first_m + in % gm;
+  tn = in / gm;
+}
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gsrc), LDS_PTR(lds_dst), 16, 0, 0);
+}
+
+template <int CW> __device__ __forceinline__ void store_bf16_row(bf16* o, const float* v) {
+  static_assert(CW % 4 == 0, "column group must be a multiple of 4");
+#pragma unroll
+  for (int q = 0; q + 8 <= CW; q += 8) {
+    bf16x8 t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[e] = f2bf(v[q + e]);
+    *(bf16x8*)(o + q) = t;
+  }
+  if (CW % 8) {
+    bf16x4 t;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t[e] = f2bf(v[CW - 4 + e]);
+    *(bf16x4*)(o + CW - 4) = t;
+  }
+}
+
+template <int CW> __device__ __forceinline__ void load_bf16_row(const bf16* a, float* h) {
+#pragma unroll
+  for (int q = 0; q + 8 <= CW; q += 8) {
+    bf16x8 t = *(const bf16x8*)(a + q);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) h[q + e] = bf2f(t[e]);
+  }
+  if (CW % 8) {
+    bf16x4 t = *(const bf16x4*)(a + CW - 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[CW - 4 + e] = bf2f(t[e]);
+  }
+}
+
+// Fused epilogue on CW consecutive columns [n, n+CW) of output row m (accumulators in v[]).
+// Epilogue semantics: include/maskdit_hip.h (enum mdt_epilogue).
+template <int CW> __device__ __forceinline__ void nt_epilogue_row(const NTParams& p, int m, int n, float* v) {
+  if (m >= p.M) return;
+  if (p.bias) {
+#pragma unroll
+    for (int q = 0; q < CW; q += 4) {
+      f32x4 b = *(const f32x4*)(p.bias + n + q);
+      v[q] += b[0]; v[q + 1] += b[1]; v[q + 2] += b[2]; v[q + 3] += b[3];
+    }
+  }
+  const int epi = p.epi;
+  if (epi == MDT_EPI_DGELU || epi == MDT_EPI_DSILU) {
+    float h[CW];
+    load_bf16_row<CW>(p.aux + (long)m * p.ldaux + n, h);
+#pragma unroll
+    for (int q = 0; q < CW; ++q) v[q] *= (epi == MDT_EPI_DGELU) ? gelu_tanh_grad(h[q]) : silu_grad(h[q]);
+  }
+  if (epi == MDT_EPI_F32) {
+    float* o = p.outf + (long)m * p.ldof + n;
+#pragma unroll
+    for (int q = 0; q < CW; q += 4) *(f32x4*)(o + q) = (f32x4){v[q], v[q + 1], v[q + 2], v[q + 3]};
+  }
+  // everything downstream sees the bf16-rounded value (it is what gets stored and re-read)
+  float y[CW];
+#pragma unroll
+  for (int q = 0; q < CW; ++q) y[q] = bf2f(f2bf(v[q]));
+  if (p.out) store_bf16_row<CW>(p.out + (long)m * p.ldo + n, y);
+  if (epi == MDT_EPI_GELU || epi == MDT_EPI_SILU) {
+    float a[CW];
+#pragma unroll
+    for (int q = 0; q < CW; ++q) a[q] = (epi == MDT_EPI_GELU) ? gelu_tanh(y[q]) : silu(y[q]);
+    store_bf16_row<CW>(p.out2 + (long)m * p.ldo2 + n, a);
+  } else if (epi == MDT_EPI_GATE_RES) {
+    const float* g = p.gate + (long)(m / p.rows_per_sample) * p.gate_ld + n;
+    const float* rs = p.res + (long)m * p.ldres + n;
+    float* o = p.outf + (long)m * p.ldof + n;
+#pragma unroll
+    for (int q = 0; q < CW; q += 4) {
+      f32x4 gv = *(const f32x4*)(g + q);
+      f32x4 rv = *(const f32x4*)(rs + q);
+      f32x4 ov;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ov[e] = rv[e] + gv[e] * y[q + e];
+      *(f32x4*)(o + q) = ov;
+    }
+  }
+}
+
+int launch_gemm_nt8(const NTParams& p, int nf, hipStream_t stream);

@@ -1,0 +1,222 @@
+// gemm_nt8: the large-problem bf16 NT GEMM (C[M,N] = A[M,K] * B[N,K]^T + fused epilogue).
+//
+// 256 x (64*NF) output tile per 512-thread workgroup (8 waves as 2(M) x 4(N); each wave owns
+// 128 x 16*NF = 8 x NF MFMA 16x16x32 fragments), K-step 64, ONE workgroup per CU.
+// Pipeline (per K-tile 4 phases, one raw s_barrier each, no vmcnt(0) in steady state):
+//
+//   * operands go HBM -> LDS by 16-byte LDS-DMA (global_load_lds) into a 2-stage ring; the ring
+//     is managed at SLOT granularity: A slot p = the 2 x 32 tile rows the two wave-rows consume
+//     in phase p (exactly one LDS-DMA instruction per wave), B = NF instructions per wave.
+//     A slot is refilled with K-tile t+2 in the phase right after its last ds_read retired, so
+//     every load has ~6 phases (1.5 K-tiles of MFMA work) to land;
+//   * phase g: [ds_read the fragments of phase g+1 into the alternate register set]
+//              [LDS-DMA refill of the slot read during phase g-1]  [4*NF MFMAs of phase g]
+//              s_waitcnt vmcnt(W_p) lgkmcnt(0) ; s_barrier
+//     W_p = number of loads issued after the one that the NEXT phase's reads depend on (loads
+//     retire in order), computed at compile time -- never 0 until the last two K-tiles;
+//   * XOR-swizzled LDS image through the *source* address (LDS-DMA destinations are lane-linear),
+//     conflict-free ds_read_b128 fragment reads; XCD-aware tile order.
+//
+// Requirements (checked by the dispatcher in gemm.hip): M % 256 == 0, N % (64*NF) == 0,
+// K % 128 == 0.  Everything else runs the 128x128 kernel in gemm.hip.
+#include "common.h"
+#include "../../include/maskdit_hip.h"
+#include "gemm_common.h"
+
+namespace {
+
+constexpr int c_issue(int p, int NF) { return 1 + (p < NF ? 1 : 0); }
+
+// steady-state vmcnt operand at the end of phase p (see header)
+constexpr int wait_count(int p, int NF) {
+  // next phase (g+1) prefetches A slot (p+2)&3 [of the current or the next K-tile], issued at
+  // phase g-6 whose phase index is (p+2)&3; the B instruction of that phase was issued after it.
+  int w = (((p + 2) & 3) < NF) ? 1 : 0;
+  for (int d = 5; d >= 0; --d) w += c_issue(((p - d) % 4 + 4) % 4, NF);
+  if (p == 2) {
+    // phase 3 also reads the whole next-tile B: its last instruction was issued at phase NF-1 of
+    // the previous K-tile; after it: one A load per phase NF..3, then phases 0..2 of this tile
+    int wb = (4 - NF) + c_issue(0, NF) + c_issue(1, NF) + c_issue(2, NF);
+    if (wb < w) w = wb;
+  }
+  return w;
+}
+
+// s_waitcnt vmcnt(N) lgkmcnt(0) as the BUILTIN (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8]
+// | vmcnt_hi[15:14]) so that hipcc's own waitcnt bookkeeping sees the LDS reads as retired and
+// does not re-wait (lgkmcnt(0)) in front of the next phase's MFMAs; the empty asm statements pin
+// the memory-operation order around it.
+template <int N> __device__ __forceinline__ void wait_vm_lgkm() {
+  static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
+  asm volatile("" ::: "memory");
+}
+
+}  // namespace
+
+template <int NF>
+__global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(NTParams p) {
+  constexpr int BN8 = 64 * NF;
+  constexpr int A_BYTES = 256 * 128;
+  constexpr int STAGE = A_BYTES + BN8 * 128;
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int tiles_m = p.M >> 8, tiles_n = p.N / BN8;
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, tm, tn);
+  const int m0 = tm << 8, n0 = tn * BN8;
+
+  // ---- LDS-DMA addressing.  One wave-instruction = 8 tile rows x 128 B; lane -> (row lane/8,
+  // LDS chunk lane%8); the global chunk is XOR-swizzled with (row & 7) = lane/8.
+  const int lr = lane >> 3, gch = (lane & 7) ^ lr;
+  // A slot q: wave w covers tile rows (w>>2)*128 + 32q + 8(w&3) .. +7
+  const int a_row0 = (wave >> 2) * 128 + 8 * (wave & 3);
+  const bf16* a_src = p.A + (long)(m0 + a_row0 + lr) * p.lda + gch * 8;
+  const long a_qstride = 32L * p.lda;
+  // B instruction j: wave w covers tile rows 64j + 8w .. +7
+  const bf16* b_src = p.B + (long)(n0 + 8 * wave + lr) * p.ldb + gch * 8;
+  const long b_jstride = 64L * p.ldb;
+  const int a_lds0 = a_row0 * 128;           // + 32q*128 + stage*STAGE
+  const int b_lds0 = A_BYTES + wave * 1024;  // + j*8192 + stage*STAGE
+
+  auto issue = [&](int stage, int kt, int ph) {
+    char* base = smem + stage * STAGE;
+    glds16(a_src + ph * a_qstride + (long)kt * 64, base + a_lds0 + ph * 4096);
+    if (ph < NF) glds16(b_src + ph * b_jstride + (long)kt * 64, base + b_lds0 + ph * 8192);
+  };
+
+  // ---- fragment read offsets (bytes inside a stage); row & 7 == fr & 7 for every fragment
+  const int fr = lane & 15, fg = lane >> 4;
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int sw = ((ks * 4 + fg) ^ (fr & 7)) << 4;
+    a_off[ks] = (wr * 128 + fr) * 128 + sw;
+    b_off[ks] = A_BYTES + (wc * 16 * NF + fr) * 128 + sw;
+  }
+
+  f32x4 acc[8][NF];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // B fragments are double-buffered across K-tiles while the register file allows it (NF <= 3);
+  // for NF = 4 the next tile's B replaces the current one inside phase 3, ks by ks.
+  constexpr bool BDB = NF < 4;
+  bf16x8 Ar[2][2][2];                // [set][frag in phase][ks]
+  bf16x8 Br[BDB ? 2 : 1][NF][2];     // [set][frag][ks]
+
+  const int nk = p.K >> 6;  // even, >= 2
+
+  // ---- prologue: K-tiles 0 and 1 in steady-state issue order
+#pragma unroll
+  for (int ph = 0; ph < 4; ++ph) issue(0, 0, ph);
+#pragma unroll
+  for (int ph = 0; ph < 4; ++ph) issue(1, 1, ph);
+  wait_vm_lgkm<4 + NF>();  // K-tile 0 landed (this wave's part)
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) Ar[0][i][ks] = *(const bf16x8*)(smem + a_off[ks] + i * 2048);
+#pragma unroll
+    for (int j = 0; j < NF; ++j) Br[0][j][ks] = *(const bf16x8*)(smem + b_off[ks] + j * 2048);
+  }
+
+#define PAIR_BODY(DRAIN)                                                                              \
+  _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                            \
+    const char* cur = smem + half * STAGE;                                                            \
+    const char* nxt = smem + (half ^ 1) * STAGE;                                                      \
+    _Pragma("unroll") for (int ph = 0; ph < 4; ++ph) {                                                \
+      /* (1) prefetch the fragments of the next phase */                                              \
+      if (ph < 3) {                                                                                   \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
+          Ar[(ph + 1) & 1][i][ks] = *(const bf16x8*)(cur + a_off[ks] + (2 * (ph + 1) + i) * 2048);    \
+      } else if (!(DRAIN && half == 1)) {                                                             \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                            \
+          _Pragma("unroll") for (int i = 0; i < 2; ++i)                                               \
+            Ar[0][i][ks] = *(const bf16x8*)(nxt + a_off[ks] + i * 2048);                              \
+          if (BDB) {                                                                                  \
+            _Pragma("unroll") for (int j = 0; j < NF; ++j)                                            \
+              Br[BDB ? (half ^ 1) : 0][j][ks] = *(const bf16x8*)(nxt + b_off[ks] + j * 2048);         \
+          }                                                                                           \
+        }                                                                                             \
+      }                                                                                               \
+      /* (2) refill the slot whose reads retired before the previous barrier */                       \
+      if (!DRAIN) issue(half, kt + half + 2, ph);                                                     \
+      /* (3) this phase's MFMAs */                                                                    \
+      __builtin_amdgcn_s_setprio(1);                                                                  \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                              \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                \
+          acc[2 * ph + i][j] = mfma16(Ar[ph & 1][i][ks], Br[BDB ? half : 0][j][ks], acc[2 * ph + i][j]); \
+        if (!BDB && ph == 3 && !(DRAIN && half == 1)) {                                               \
+          _Pragma("unroll") for (int j = 0; j < NF; ++j)                                              \
+            Br[0][j][ks] = *(const bf16x8*)(nxt + b_off[ks] + j * 2048);                              \
+        }                                                                                             \
+      }                                                                                               \
+      __builtin_amdgcn_s_setprio(0);                                                                  \
+      /* (4) publish: my share of the next phase's data has landed, my LDS reads have retired */      \
+      if (DRAIN) wait_vm_lgkm<0>();                                                                   \
+      else if (ph == 0) wait_vm_lgkm<wait_count(0, NF)>();                                            \
+      else if (ph == 1) wait_vm_lgkm<wait_count(1, NF)>();                                            \
+      else if (ph == 2) wait_vm_lgkm<wait_count(2, NF)>();                                            \
+      else wait_vm_lgkm<wait_count(3, NF)>();                                                         \
+      __builtin_amdgcn_s_barrier();                                                                   \
+      asm volatile("" ::: "memory");                                                                  \
+    }                                                                                                 \
+  }
+
+  int kt = 0;
+  for (; kt + 2 < nk; kt += 2) { PAIR_BODY(false) }
+  { PAIR_BODY(true) }
+#undef PAIR_BODY
+
+  // ---- epilogue: restage each 16-row fragment band through LDS (all stages are free now) so
+  // that a lane owns 4*NF consecutive columns of one row, then run the shared fused epilogue.
+  constexpr int WN = 16 * NF;       // wave tile width
+  constexpr int SP = WN + 4;        // padded row pitch (floats)
+  float* stg = (float*)(smem + wave * (16 * SP * 4));
+  const int er = lane >> 2, ec = (lane & 3) * (4 * NF);
+  const int n = n0 + wc * WN + ec;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) stg[(fg * 4 + r) * SP + j * 16 + fr] = acc[i][j][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private staging: no barrier needed
+    float v[4 * NF];
+#pragma unroll
+    for (int q = 0; q < NF; ++q) {
+      f32x4 t = *(const f32x4*)(stg + er * SP + ec + q * 4);
+      v[q * 4 + 0] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int m = m0 + wr * 128 + i * 16 + er;
+    nt_epilogue_row<4 * NF>(p, m, n, v);
+  }
+}
+
+template __global__ void gemm_nt8_kernel<2>(NTParams);
+template __global__ void gemm_nt8_kernel<3>(NTParams);
+template __global__ void gemm_nt8_kernel<4>(NTParams);
+
+int launch_gemm_nt8(const NTParams& p, int nf, hipStream_t stream) {
+  const int tiles = (p.M >> 8) * (p.N / (64 * nf));
+  switch (nf) {
+    case 2: hipLaunchKernelGGL(gemm_nt8_kernel<2>, dim3(tiles), dim3(512), 0, stream, p); break;
+    case 3: hipLaunchKernelGGL(gemm_nt8_kernel<3>, dim3(tiles), dim3(512), 0, stream, p); break;
+    default: hipLaunchKernelGGL(gemm_nt8_kernel<4>, dim3(tiles), dim3(512), 0, stream, p); break;
+  }
+  return mdt_check_launch("gemm_nt8");
+}

@@ -160,19 +160,45 @@ __global__ __launch_bounds__(256) void ln_modulate_bwd_kernel(const bf16* __rest
 }
 
 // ------------------------------------------------------------------------------------------
-// grid (B, splits, column blocks of 1024): thread owns a float4 column quad, loops over rows.
+// One workgroup per (sample b, 128-column strip): 256 threads = 32 column quads x 8 row lanes; a
+// thread streams rows rl, rl+8, ... (4-way unrolled so several 16-byte loads are in flight),
+// keeps its dgate / dbias partial sums in registers, and the 8 row lanes are combined through
+// LDS.  One atomic per (b, column) for dgate (uncontended) and B-way contention for dbias.
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dx, const bf16* __restrict__ y,
                                                        const float* __restrict__ gate, int mod_ld, int rows_per_sample,
-                                                       int chunk, bf16* __restrict__ dys, float* __restrict__ dgate,
+                                                       bf16* __restrict__ dys, float* __restrict__ dgate,
                                                        int dmod_ld, float* __restrict__ dbias, int D) {
+  __shared__ float red[2][8][128];
   const int b = blockIdx.x;
-  const int cq = blockIdx.z * 256 + threadIdx.x;
-  if (cq * 4 >= D) return;
-  const int r_begin = blockIdx.y * chunk, r_end = min(r_begin + chunk, rows_per_sample);
-  const f32x4 g = *(const f32x4*)(gate + (long)b * mod_ld + 4 * cq);
+  const int cq = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int col = blockIdx.y * 128 + 4 * cq;
+  const f32x4 g = *(const f32x4*)(gate + (long)b * mod_ld + col);
   f32x4 ag = (f32x4){0.f, 0.f, 0.f, 0.f}, ab = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int r = r_begin; r < r_end; ++r) {
-    const long off = ((long)b * rows_per_sample + r) * D + 4 * cq;
+  const long base = (long)b * rows_per_sample * D + col;
+  int r = rl;
+  for (; r + 24 < rows_per_sample; r += 32) {
+    f32x4 d[4];
+    bf16x4 yv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long off = base + (long)(r + 8 * u) * D;
+      d[u] = *(const f32x4*)(dx + off);
+      yv[u] = *(const bf16x4*)(y + off);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      bf16x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ag[e] += d[u][e] * bf2f(yv[u][e]);
+        o[e] = f2bf(d[u][e] * g[e]);
+        ab[e] += bf2f(o[e]);
+      }
+      *(bf16x4*)(dys + base + (long)(r + 8 * u) * D) = o;
+    }
+  }
+  for (; r < rows_per_sample; r += 8) {
+    const long off = base + (long)r * D;
     f32x4 d = *(const f32x4*)(dx + off);
     bf16x4 yv = *(const bf16x4*)(y + off);
     bf16x4 o;
@@ -186,9 +212,17 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    atomic_add_f32(dgate + (long)b * dmod_ld + 4 * cq + e, ag[e]);
-    if (dbias) atomic_add_f32(dbias + 4 * cq + e, ab[e]);
+    red[0][rl][4 * cq + e] = ag[e];
+    red[1][rl][4 * cq + e] = ab[e];
   }
+  __syncthreads();
+  const int c = threadIdx.x & 127, which = threadIdx.x >> 7;
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s += red[which][k][c];
+  const int oc = blockIdx.y * 128 + c;
+  if (which == 0) atomic_add_f32(dgate + (long)b * dmod_ld + oc, s);
+  else if (dbias) atomic_add_f32(dbias + oc, s);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -260,13 +294,12 @@ extern "C" int mdt_gate_bwd(const float* dx, const mdt_bf16* y, const float* gat
                             mdt_bf16* dys, float* dgate, int dmod_ld, float* dbias, int M, int D,
                             mdt_stream_t stream) {
   MDT_REQUIRE(dx && y && gate && dys && dgate, "gate_bwd: null pointer");
-  MDT_REQUIRE(D % 4 == 0, "gate_bwd: D must be a multiple of 4");
+  MDT_REQUIRE(D % 128 == 0, "gate_bwd: D must be a multiple of 128");
   MDT_REQUIRE(M > 0 && rows_per_sample > 0 && M % rows_per_sample == 0, "gate_bwd: M must be B*rows_per_sample");
   int B = M / rows_per_sample;
-  int chunk = pick_chunk(B, rows_per_sample);
-  dim3 grid(B, cdiv(rows_per_sample, chunk), cdiv(D / 4, 256));
+  dim3 grid(B, D / 128);
   hipLaunchKernelGGL(gate_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dx, (const bf16*)y, gate, mod_ld,
-                     rows_per_sample, chunk, (bf16*)dys, dgate, dmod_ld, dbias, D);
+                     rows_per_sample, (bf16*)dys, dgate, dmod_ld, dbias, D);
   return mdt_check_launch("gate_bwd");
 }
 

@@ -1,0 +1,85 @@
+"""A/B micro-benchmark + cross-check of the two NT GEMM kernels (run on the GPU box).
+    python tools/gemm_bench.py [--iters 20]
+For every shape: variant 1 (128x128 tile) vs variant 2 (256-row phase-pipelined), interleaved
+rounds, median time -> TFLOP/s; outputs compared with each other and with torch fp32 matmul."""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from maskdit_amd import _lib, ops  # noqa: E402
+
+SHAPES = [  # (M, N, K, tag)
+    (256, 256, 128, 'minimal nf4'), (512, 384, 256, 'small nf3'), (1024, 640, 384, 'small nf2'),
+    (32768, 3456, 1152, 'XL qkv'), (32768, 1152, 1152, 'XL proj'), (32768, 4608, 1152, 'XL fc1'),
+    (32768, 1152, 4608, 'XL fc2'), (65536, 1536, 512, 'dec qkv'), (65536, 512, 512, 'dec proj'),
+    (65536, 2048, 512, 'dec fc1'), (65536, 512, 2048, 'dec fc2'), (8192, 8192, 8192, '8k cube'),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--iters', type=int, default=10)
+    ap.add_argument('--rounds', type=int, default=3)
+    args = ap.parse_args()
+    L = _lib.lib()
+    dev = 'cuda'
+    torch.manual_seed(0)
+    ev = [C.c_void_p() for _ in range(2)]
+    for e in ev:
+        L.mdt_event_create(C.byref(e))
+    st = torch.cuda.current_stream().cuda_stream
+    print(f'{"shape":34s} {"v1 TF/s":>9s} {"v8 TF/s":>9s} {"ratio":>6s}  v8-v1 maxdiff   v8-ref relerr')
+    for M, N, K, tag in SHAPES:
+        A = (torch.rand(M, K, device=dev) * 2 - 1).to(torch.bfloat16)
+        W = (torch.rand(N, K, device=dev) * 2 - 1).to(torch.bfloat16)
+        b = torch.randn(N, device=dev)
+        outs = {}
+        times = {1: [], 2: []}
+        for r in range(args.rounds):
+            for v in (1, 2):
+                L.mdt_set_tuning(b'gemm_nt_variant', v)
+                out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+                ops.gemm_nt(A, W, b, ops.EPI_BF16, out=out)  # warm
+                L.mdt_event_record(ev[0], st)
+                for _ in range(args.iters):
+                    ops.gemm_nt(A, W, b, ops.EPI_BF16, out=out)
+                L.mdt_event_record(ev[1], st)
+                ms = C.c_float()
+                L.mdt_event_elapsed_ms(ev[0], ev[1], C.byref(ms))
+                times[v].append(ms.value / args.iters)
+                outs[v] = out
+        tf = {v: 2.0 * M * N * K / (sorted(times[v])[len(times[v]) // 2] * 1e-3) / 1e12 for v in (1, 2)}
+        d = (outs[2].float() - outs[1].float()).abs().max().item()
+        rows = min(M, 2048)
+        ref = A[:rows].float() @ W.float().t() + b
+        rel = ((outs[2][:rows].float() - ref).abs().max() / ref.abs().max()).item()
+        print(f'{str((M, N, K)) + " " + tag:34s} {tf[1]:9.1f} {tf[2]:9.1f} {tf[2] / tf[1]:6.2f}  {d:12.3e}   {rel:10.3e}', flush=True)
+    # fused epilogues on the pipelined kernel vs the 128x128 kernel (same arithmetic => same bits expected)
+    M, N, K, Lr = 4096, 1152, 1152, 128
+    A = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
+    b = torch.randn(N, device=dev) * 0.1
+    res = torch.randn(M, N, device=dev)
+    gate = torch.randn(M // Lr, 3 * N, device=dev)
+    aux = torch.randn(M, N, device=dev).to(torch.bfloat16)
+    for name, kw in [('F32', dict(epi=ops.EPI_F32)), ('GELU', dict(epi=ops.EPI_GELU)), ('SILU', dict(epi=ops.EPI_SILU)),
+                     ('GATE_RES', dict(epi=ops.EPI_GATE_RES, res=res, gate=gate[:, N:], gate_ld=3 * N, rows_per_sample=Lr)),
+                     ('DGELU', dict(epi=ops.EPI_DGELU, aux=aux)), ('DSILU', dict(epi=ops.EPI_DSILU, aux=aux))]:
+        got = {}
+        for v in (1, 2):
+            L.mdt_set_tuning(b'gemm_nt_variant', v)
+            got[v] = ops.gemm_nt(A, W, b if 'D' != name[0] else None, **kw)
+        worst = 0.0
+        for x, y in zip(got[1], got[2]):
+            if x is not None:
+                worst = max(worst, (x.float() - y.float()).abs().max().item())
+        print(f'epilogue {name:9s} v8 vs v1 max abs diff {worst:.3e}')
+    L.mdt_set_tuning(b'gemm_nt_variant', 0)
+
+
+if __name__ == '__main__':
+    main()
