@@ -1,0 +1,91 @@
+#!/usr/bin/env python
+"""generate.py -- the reference's sampling entry point (generate.py:18-91, sample.py:230-296) on
+the MI355X engine: per-seed StackedRandomGenerator latents / labels (utils.py:119-133), the
+hipGraph-captured EDM Heun sampler with classifier-free guidance, latents written as .npy.
+
+    python generate.py --config configs/xl2-256-synthetic.yaml --seeds 0-63 --num_steps 50 --cfg_scale 1.5 \
+        [--ckpt_path 2000000.pt] [--outdir samples]
+
+The VAE decode + PNG step of the reference (sample.py:273-296) is out of scope (weights are not
+available offline): the fp64 latents `z` are the product."""
+from __future__ import annotations
+
+import argparse
+import os
+import time
+
+import numpy as np
+import torch
+
+import maskdit_amd as M
+from maskdit_amd.schedule import load_config
+
+
+class StackedRandomGenerator:
+    """utils.py:119-133: one torch.Generator per sample seed, draws stacked along the batch."""
+
+    def __init__(self, device, seeds):
+        self.generators = [torch.Generator(device).manual_seed(int(s) % (1 << 32)) for s in seeds]
+
+    def randn(self, size, **kw):
+        assert size[0] == len(self.generators)
+        return torch.stack([torch.randn(size[1:], generator=g, **kw) for g in self.generators])
+
+    def randn_like(self, x):
+        return self.randn(x.shape, dtype=x.dtype, layout=x.layout, device=x.device)
+
+    def randint(self, *a, size, **kw):
+        assert size[0] == len(self.generators)
+        return torch.stack([torch.randint(*a, size=size[1:], generator=g, **kw) for g in self.generators])
+
+
+def parse_seeds(s):
+    out = []
+    for part in s.split(','):
+        if '-' in part:
+            a, b = part.split('-')
+            out += list(range(int(a), int(b) + 1))
+        else:
+            out.append(int(part))
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--config', required=True)
+    ap.add_argument('--ckpt_path', default=None)
+    ap.add_argument('--outdir', default='samples')
+    ap.add_argument('--seeds', type=parse_seeds, default=list(range(64)))
+    ap.add_argument('--max_batch_size', type=int, default=64)
+    ap.add_argument('--num_steps', type=int, default=50)
+    ap.add_argument('--cfg_scale', type=float, default=None)
+    ap.add_argument('--class_idx', type=int, default=None)
+    args = ap.parse_args()
+    cfg = load_config(args.config)
+    dev = torch.device('cuda', 0)
+    mc = cfg.model
+    net = M.Precond_models[mc.precond](img_resolution=mc.in_size, img_channels=mc.in_channels, num_classes=mc.num_classes,
+                                       model_type=mc.model_type, use_decoder=mc.use_decoder, mae_loss_coef=mc.mae_loss_coef,
+                                       pad_cls_token=mc.pad_cls_token).to(dev).eval()
+    if args.ckpt_path:
+        net.load_state_dict(torch.load(args.ckpt_path, map_location='cpu')['ema'])
+    os.makedirs(args.outdir, exist_ok=True)
+    t0, n = time.time(), 0
+    for i in range(0, len(args.seeds), args.max_batch_size):
+        seeds = args.seeds[i:i + args.max_batch_size]
+        rnd = StackedRandomGenerator(dev, seeds)
+        latents = rnd.randn([len(seeds), net.img_channels, net.img_resolution, net.img_resolution], device=dev)
+        labels = torch.eye(net.num_classes, device=dev)[rnd.randint(net.num_classes, size=[len(seeds)], device=dev)]
+        if args.class_idx is not None:
+            labels[:, :] = 0
+            labels[:, args.class_idx] = 1
+        z = M.edm_sampler(net, latents, labels, cfg_scale=args.cfg_scale, randn_like=rnd.randn_like, num_steps=args.num_steps)
+        for s, zi in zip(seeds, z.cpu().numpy()):
+            np.save(os.path.join(args.outdir, f'{s:06d}.npy'), zi)
+        n += len(seeds)
+    torch.cuda.synchronize()
+    print(f'{n} latents, {args.num_steps} steps, cfg={args.cfg_scale}: {n / (time.time() - t0):.2f} samples/s')
+
+
+if __name__ == '__main__':
+    main()

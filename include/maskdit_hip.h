@@ -174,6 +174,13 @@ int mdt_scale_rows(const float* x, const float* coef, int coef_idx, float* out, 
 int mdt_precond_out(const float* x, const float* F, const float* coef, float* D, int B, int chw,
                     mdt_stream_t stream);
 
+/* utils.sample (utils.py:59-65): moments [B,2C,R,R] -> z = scale*(mean + exp(.5*clamp(logvar,-30,20))*randn),
+ * chw = C*R*R, randn drawn by the caller (torch.randn_like(mean), same stream position as the reference). */
+int mdt_sample_moments(const float* moments, const float* randn, float* z, int B, int chw, float scale,
+                       mdt_stream_t stream);
+/* class dropout (train.py:208-209): y[b,:] *= (u[b] >= p), u = torch.rand(B,1) drawn by the caller. */
+int mdt_class_dropout(float* y, const float* u, float p, int B, int num_classes, mdt_stream_t stream);
+
 /* ---------------------------------------------------------------- optimizer ------------- */
 
 /* apex FusedAdam(adam_w_mode=True) step (train.py:141,226) fused with update_ema

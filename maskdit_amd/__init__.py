@@ -9,6 +9,7 @@ reference's Python surface:
     FusedAdam, update_ema                                        <- apex.optimizers, train_utils/helper.py
     edm_sampler                                                  <- sample.py
     DataParallel                                                 <- accelerate / DDP (train.py:178)
+    sample, class_dropout_                                       <- utils.py:59-65, train.py:208-209
 
 There is no non-HIP fallback: computing without libmaskdit_hip.so or off-GPU raises.
 """
@@ -20,3 +21,4 @@ from .loss import EDMLoss, Losses, unwrap_model  # noqa: F401
 from .optim import FusedAdam, update_ema  # noqa: F401
 from .sampler import edm_sampler  # noqa: F401
 from .ddp import DataParallel, GradSlabReducer  # noqa: F401
+from .latents import class_dropout_, sample  # noqa: F401

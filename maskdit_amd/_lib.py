@@ -60,6 +60,8 @@ _PROTOS = {
     'mdt_precond_coef': [vp, vp, i32, f32],
     'mdt_scale_rows': [vp, vp, i32, vp, i32, i32],
     'mdt_precond_out': [vp, vp, vp, vp, i32, i32],
+    'mdt_sample_moments': [vp, vp, vp, i32, i32, f32],
+    'mdt_class_dropout': [vp, vp, f32, i32, i32],
     'mdt_adamw_ema_step': [vp, vp, vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, f32, f32, f32, f32],
     'mdt_ema_update': [vp, vp, i64, f32],
     'mdt_transpose_bf16_batched': [vp, vp, vp, i32, i32],

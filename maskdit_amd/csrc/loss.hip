@@ -235,3 +235,43 @@ extern "C" int mdt_edm_loss_bwd(const float* dloss, const float* D, const float*
                      mae_coef, dF, C, R, p);
   return mdt_check_launch("edm_loss_bwd");
 }
+
+// ------------------------------------------------------------------------------------------
+// utils.sample (utils.py:59-65): moments [B, 2C, R, R] = (mean | logvar);
+// z = scale * (mean + exp(0.5 * clamp(logvar, -30, 20)) * randn)      (randn drawn by the caller)
+__global__ void sample_moments_kernel(const float* __restrict__ moments, const float* __restrict__ rn,
+                                      float* __restrict__ z, int B, int chw, float scale) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n = (long)B * chw;
+  if (idx >= n) return;
+  const int b = (int)(idx / chw);
+  const int r = (int)(idx - (long)b * chw);
+  const float mean = moments[(long)b * 2 * chw + r];
+  float logvar = moments[(long)b * 2 * chw + chw + r];
+  logvar = fminf(fmaxf(logvar, -30.f), 20.f);
+  z[idx] = scale * (mean + expf(0.5f * logvar) * rn[idx]);
+}
+
+extern "C" int mdt_sample_moments(const float* moments, const float* randn, float* z, int B, int chw, float scale,
+                                  mdt_stream_t stream) {
+  MDT_REQUIRE(moments && randn && z && B > 0 && chw > 0, "sample_moments: bad arguments");
+  long n = (long)B * chw;
+  hipLaunchKernelGGL(sample_moments_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, moments, randn, z, B,
+                     chw, scale);
+  return mdt_check_launch("sample_moments");
+}
+
+// class dropout (train.py:208-209): y[b, :] *= (u[b] >= p)
+__global__ void class_dropout_kernel(float* __restrict__ y, const float* __restrict__ u, float p, int B, int nc) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)B * nc) return;
+  const int b = (int)(idx / nc);
+  if (!(u[b] >= p)) y[idx] = 0.f;
+}
+
+extern "C" int mdt_class_dropout(float* y, const float* u, float p, int B, int num_classes, mdt_stream_t stream) {
+  MDT_REQUIRE(y && u && B > 0 && num_classes > 0, "class_dropout: bad arguments");
+  long n = (long)B * num_classes;
+  hipLaunchKernelGGL(class_dropout_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, y, u, p, B, num_classes);
+  return mdt_check_launch("class_dropout");
+}

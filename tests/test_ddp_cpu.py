@@ -1,0 +1,122 @@
+"""N > 1 path on CPU: world_size-2 `gloo` process groups exercising the data-parallel protocol
+of maskdit_amd/ddp.py (slab-wise asynchronous gradient averaging, no_sync accumulation, rank-0
+parameter broadcast) with a stand-in engine that owns the same flat arenas / slab table as the
+HIP engine.  The arithmetic on the slabs is torch here; on the GPU box the same wrapper runs
+over RCCL with the real engine."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class FakeEngine:
+    """Arena + slab layout of the real Engine (maskdit_amd/engine.py Layout) without HIP."""
+
+    def __init__(self, spec):
+        from maskdit_amd.engine import Layout
+        self.lay = Layout(spec)
+        self.P = torch.zeros(self.lay.n)
+        self.G = None
+        self.grad_slab_hook = None
+        self.shadows_dirty = False
+
+    def ensure_grad(self):
+        if self.G is None:
+            self.G = torch.zeros(self.lay.n)
+        return self.G
+
+    def backward_order(self):
+        sp = self.lay.sp
+        names = [f'dec{i}' for i in reversed(range(sp.ddepth))] + [f'enc{i}' for i in reversed(range(sp.depth))] + ['ada', 'misc']
+        return [(n,) + self.lay.slabs[n] for n in names]
+
+    def fake_backward(self, rank, step):
+        """Accumulate a deterministic per-rank 'gradient' slab by slab, announcing each slab."""
+        for name, lo, hi in self.backward_order():
+            self.G[lo:hi] += torch.arange(lo, hi, dtype=torch.float32) * 1e-6 * (rank + 1) + step
+            if self.grad_slab_hook is not None:
+                self.grad_slab_hook(name, lo, hi)
+
+
+class FakeModule(torch.nn.Module):
+    def __init__(self, eng):
+        super().__init__()
+        self._eng = eng
+
+    def engine(self):
+        return self._eng
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from maskdit_amd.engine import make_spec
+        from maskdit_amd.ddp import DataParallel
+        spec = make_spec('DiT-S/2', 32, 4, 1000)
+        eng = FakeEngine(spec)
+        eng.P.fill_(float(rank + 1))  # replicas start different: construction must broadcast rank 0's
+        dp = DataParallel(FakeModule(eng))
+        assert torch.all(eng.P == 1.0), 'parameter arena was not broadcast from rank 0'
+        assert eng.shadows_dirty
+        n = eng.lay.n
+        covered = torch.zeros(n, dtype=torch.bool)
+        for _, lo, hi in eng.backward_order():
+            assert not covered[lo:hi].any(), 'slabs overlap'
+            covered[lo:hi] = True
+        assert covered.all(), 'slabs do not cover the gradient arena'
+        idx = torch.arange(n, dtype=torch.float32)
+        # --- plain step: every slab reduced once, result = mean over ranks
+        eng.fake_backward(rank, step=0.0)
+        dp.finish_grad_sync()
+        want = idx * 1e-6 * (sum(r + 1 for r in range(world)) / world)
+        assert torch.allclose(eng.G, want, rtol=1e-6, atol=1e-9)
+        assert dp.reducer.reduced_elems == n
+        # --- gradient accumulation: two local micro-steps under no_sync, the third reduces
+        eng.G.zero_()
+        dp.reducer.reduced_elems = 0
+        with dp.no_sync():
+            eng.fake_backward(rank, step=1.0)
+            eng.fake_backward(rank, step=2.0)
+        assert dp.reducer.reduced_elems == 0 and not dp.reducer.pending
+        eng.fake_backward(rank, step=3.0)
+        dp.finish_grad_sync()
+        want = 3 * idx * 1e-6 * (sum(r + 1 for r in range(world)) / world) + 6.0
+        assert torch.allclose(eng.G, want, rtol=1e-5, atol=1e-6)
+        assert dp.reducer.reduced_elems == n
+        q.put((rank, 'ok'))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, 'FAIL: ' + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_grad_slab_allreduce_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert all(r[1] == 'ok' for r in res), res
+
+
+def test_single_process_is_passthrough():
+    from maskdit_amd.engine import make_spec
+    from maskdit_amd.ddp import DataParallel
+    eng = FakeEngine(make_spec('DiT-S/2', 32, 4, 1000))
+    dp = DataParallel(FakeModule(eng))
+    eng.fake_backward(0, 0.0)
+    dp.finish_grad_sync()
+    assert dp.reducer.world == 1 and dp.reducer.reduced_elems == 0

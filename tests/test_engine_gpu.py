@@ -250,3 +250,26 @@ def test_fails_loudly_off_gpu():
     net = M.Precond_models['edm'](img_resolution=32, img_channels=4, num_classes=1000, model_type='DiT-S/2')
     with pytest.raises(M.MaskDiTLibError):
         net(torch.zeros(1, 4, 32, 32), torch.ones(1))
+
+
+def test_sample_moments_and_class_dropout_vs_reference_fixture(golden_dir):
+    g = _load(golden_dir, 'moments.npz')  # produced by the reference's utils.sample (seed 11)
+    mom = torch.from_numpy(g['moments']).to(DEV)
+    torch.manual_seed(11)
+    rn_ref = torch.randn(4, 4, 32, 32, device=DEV)  # device philox stream differs from the CPU fixture's draw ...
+    from maskdit_amd._lib import call
+    z = torch.empty(4, 4, 32, 32, device=DEV)
+    rn = torch.from_numpy(g['randn']).to(DEV)       # ... so feed the fixture's own randn to the kernel
+    call('mdt_sample_moments', mom.data_ptr(), rn.data_ptr(), z.data_ptr(), 4, 4 * 32 * 32, 0.18215,
+         torch.cuda.current_stream().cuda_stream)
+    np.testing.assert_allclose(z.cpu().numpy(), g['z'], rtol=2e-6, atol=2e-6)
+    torch.manual_seed(11)
+    z2 = M.sample(mom)  # draws randn_like(mean) itself: same draw as torch.randn on the device
+    ref2 = O.sample_moments(mom.cpu(), rn_ref.cpu())
+    np.testing.assert_allclose(z2.cpu().numpy(), ref2.numpy(), rtol=2e-6, atol=2e-6)
+    y = torch.eye(1000, device=DEV)[:64].contiguous()
+    torch.manual_seed(3)
+    u = torch.rand(64, 1, device=DEV)
+    torch.manual_seed(3)
+    M.class_dropout_(y, 0.3)
+    assert torch.equal(y, torch.eye(1000, device=DEV)[:64] * (u >= 0.3).float())

@@ -1,0 +1,135 @@
+#!/usr/bin/env python
+"""train.py -- the reference's training entry point (train.py:35-336) on the MI355X engine.
+
+    python train.py --config configs/xl2-256-synthetic.yaml [--results_dir results] [--ckpt_path x.pt]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py --config ...
+
+Same YAML schema, same step body (train.py:200-230: sample -> class dropout -> micro-batches ->
+loss -> backward -> lr warm-up -> optimizer step -> EMA), same checkpoint dict
+({"model","ema","opt","args"} as `{step:07d}.pt`), same throughput log line (steps/sec after a
+device sync every `log_every` steps).  Data: `data.category: synthetic` draws latent moments on the
+device (the LMDB / WebDataset loaders are out of scope).  One process per GPU;
+gradient averaging = maskdit_amd.DataParallel (RCCL), no accelerate / apex / omegaconf needed."""
+from __future__ import annotations
+
+import argparse
+import copy
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+import maskdit_amd as M
+from maskdit_amd.schedule import get_mask_ratio_fn, get_one_hot, load_config, lr_rampup_factor
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--config', required=True)
+    ap.add_argument('--results_dir', default='results')
+    ap.add_argument('--exp_name', default='run')
+    ap.add_argument('--ckpt_path', default=None)
+    ap.add_argument('--global_seed', type=int, default=0)
+    ap.add_argument('--max_num_steps', type=int, default=None)
+    args = ap.parse_args()
+    cfg = load_config(args.config)
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    dev = torch.device('cuda', local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+    torch.manual_seed(args.global_seed)  # same seed on every rank, as train.py:67-68
+
+    mc, tc = cfg.model, cfg.train
+    net = M.Precond_models[mc.precond](img_resolution=mc.in_size, img_channels=mc.in_channels, num_classes=mc.num_classes,
+                                       model_type=mc.model_type, use_decoder=mc.use_decoder, mae_loss_coef=mc.mae_loss_coef,
+                                       pad_cls_token=mc.pad_cls_token, ext_feature_dim=mc.get('ext_feature_dim', 0)).to(dev)
+    ema = copy.deepcopy(net).eval()
+    for p in ema.parameters():
+        p.requires_grad_(False)
+    opt = M.FusedAdam(net.parameters(), lr=tc.lr, adam_w_mode=True, weight_decay=0)
+    step0 = 0
+    if args.ckpt_path:
+        ck = torch.load(args.ckpt_path, map_location='cpu')
+        net.load_state_dict(ck['model'])
+        ema.load_state_dict(ck['ema'])
+        if 'opt' in ck:
+            opt.load_state_dict(ck['opt'])
+        step0 = int(os.path.basename(args.ckpt_path).split('.')[0]) if os.path.basename(args.ckpt_path)[:7].isdigit() else 0
+    M.update_ema(ema, net, decay=0)  # train.py:188
+    opt.fuse_ema(ema, 0.9999)
+    model = M.DataParallel(net) if world > 1 else net
+    net.train()
+    loss_fn = M.Losses['edm']()
+    mask_ratio_fn = get_mask_ratio_fn(mc.get('mask_ratio_fn', 'constant'), mc.mask_ratio, mc.get('mask_ratio_min', 0))
+    accum = tc.get('grad_accum', 1)
+    mb = tc.batchsize
+    global_batch = mb * accum * world
+    max_steps = args.max_num_steps or tc.get('max_num_steps', 100)
+    exp_dir = os.path.join(args.results_dir, args.exp_name)
+    if rank == 0:
+        os.makedirs(os.path.join(exp_dir, 'checkpoints'), exist_ok=True)
+        print(f'{mc.model_type} params {sum(p.numel() for p in net.parameters()):,}  global batch {global_batch} '
+              f'({world} GPU x {mb} x accum {accum})', flush=True)
+
+    R, C = mc.in_size, mc.in_channels
+    gen = torch.Generator(device=dev).manual_seed(1 + rank)
+
+    def batch():  # (moments [B,2C,R,R], one-hot labels) as the latent datasets yield them (datasets.py:184-192)
+        B = mb * accum
+        mom = torch.cat([2.745 * torch.randn(B, C, R, R, device=dev, generator=gen), torch.full((B, C, R, R), -10.0, device=dev)], 1)
+        return mom, get_one_hot(torch.randint(0, mc.num_classes, (B,), device=dev, generator=gen), mc.num_classes)
+
+    step, log_steps, running = step0, 0, torch.zeros((), device=dev)
+    t0 = time.time()
+    while step < max_steps:
+        x, y = batch()
+        x = M.sample(x)                                        # train.py:203
+        opt.zero_grad(set_to_none=True)                        # train.py:206
+        ratio = mask_ratio_fn(step / max_steps)
+        M.class_dropout_(y, mc.class_dropout_prob)             # train.py:208-209
+        for a in range(accum):
+            xs, ys = x[a * mb:(a + 1) * mb], y[a * mb:(a + 1) * mb].contiguous()
+            sync = a == accum - 1
+            if world > 1 and not sync:
+                with model.no_sync():
+                    (loss_fn(model, xs, ys, mask_ratio=ratio, mae_loss_coef=mc.mae_loss_coef).mean() / accum).backward()
+                continue
+            loss = loss_fn(model, xs, ys, mask_ratio=ratio, mae_loss_coef=mc.mae_loss_coef)
+            (loss.mean() / accum).backward()
+            running += loss.detach().mean()
+        if world > 1:
+            model.finish_grad_sync()
+        for g in opt.param_groups:                             # train.py:223-225
+            g['lr'] = tc.lr * lr_rampup_factor(step, global_batch, tc.get('lr_rampup_kimg', 0))
+        opt.step()
+        M.update_ema(ema, net)                                 # folded into opt.step()
+        step += 1
+        log_steps += 1
+        if step % cfg.log.log_every == 0:
+            torch.cuda.synchronize()
+            sps = log_steps / (time.time() - t0)
+            avg = running / log_steps
+            if world > 1:
+                dist.all_reduce(avg, op=dist.ReduceOp.SUM)
+                avg = avg / world
+            if rank == 0:
+                print(f'(step={step:07d}) Train Loss: {avg.item():.4f}, Train Steps/Sec: {sps:.2f}, '
+                      f'img/s: {sps * global_batch:.1f}, mem: {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB', flush=True)
+            running.zero_()
+            log_steps, t0 = 0, time.time()
+        if step % cfg.log.ckpt_every == 0 and rank == 0:
+            torch.save({'model': net.state_dict(), 'ema': ema.state_dict(), 'opt': opt.state_dict(), 'args': vars(args)},
+                       os.path.join(exp_dir, 'checkpoints', f'{step:07d}.pt'))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
