@@ -26,7 +26,8 @@ const char* mdt_last_error(void);
 int mdt_version(void);
 /* Process-wide tuning knobs (benchmarking / A-B tests only; defaults are the product path).
  * "gemm_nt_variant": 0 = auto, 1 = force the 128x128-tile kernel, 2 = force the 256-row
- * phase-pipelined kernel wherever its shape constraints hold. */
+ * phase-pipelined kernel wherever its shape constraints hold.
+ * "gemm_tn_variant": 0 = auto, 1 = force the 128x128-tile weight-gradient kernel. */
 int mdt_set_tuning(const char* key, int value);
 
 /* ---------------------------------------------------------------- GEMMs (MFMA bf16) ---- */

@@ -286,6 +286,11 @@ extern "C" int mdt_gemm_tn(const mdt_gemm_tn_args* a, mdt_stream_t stream) {
   p.M = a->M; p.N1 = a->N1; p.N2 = a->N2; p.C = a->C; p.ldc = a->ldc;
   p.n1_valid = a->n1_valid > 0 ? a->n1_valid : a->N1;
   p.n2_valid = a->n2_valid > 0 ? a->n2_valid : a->N2;
+  const int tn_variant = mdt_get_tuning_int(MDT_TUNE_GEMM_TN_VARIANT);
+  if (tn_variant != 1 && p.n1_valid == a->N1 && p.n2_valid == a->N2 && a->N1 % 128 == 0 && a->N2 % 128 == 0 &&
+      a->M % 32 == 0 && a->M >= 8192 && (long)a->N1 * a->N2 >= 256L * 1024) {
+    return launch_gemm_tn8(p.A, p.lda, p.B, p.ldb, p.M, p.N1, p.N2, p.C, p.ldc, (hipStream_t)stream);
+  }
   int tiles = cdiv(a->N1, BM) * cdiv(a->N2, BN);
   int ksteps = a->M / BK;
   int splits = a->splits;

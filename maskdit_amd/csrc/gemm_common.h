@@ -124,3 +124,5 @@ template <int CW> __device__ __forceinline__ void nt_epilogue_row(const NTParams
 }
 
 int launch_gemm_nt8(const NTParams& p, int nf, hipStream_t stream);
+int launch_gemm_tn8(const bf16* A, int lda, const bf16* B, int ldb, int M, int N1, int N2, float* C, int ldc,
+                    hipStream_t stream);

@@ -1,0 +1,112 @@
+"""CPU checks of the host logic around the HIP path: arena layout vs the oracle's (reference)
+state-dict shapes, slab coverage for the DP all-reduce, schedules, config loader, module
+surface (state-dict keys, attributes the reference callers read), loud failure without a GPU."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import maskdit_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize('model,R', [('DiT-S/2', 32), ('DiT-XL/2', 32), ('DiT-XL/2', 64), ('DiT-B/2', 32), ('DiT-L/2', 32)])
+def test_arena_layout_matches_reference_state_dict(model, R):
+    from maskdit_amd.engine import Layout, make_spec, param_table
+    sp = make_spec(model, R, 4, 1000)
+    cfg = O.make_cfg(model, img_resolution=R)
+    ref = {k: v for k, v in O.param_shapes(cfg).items() if k not in O.NON_TRAINABLE}
+    tab = dict(param_table(sp))
+    assert tab == ref  # same keys, same shapes as the reference checkpoint layout
+    lay = Layout(sp)
+    spans = sorted((lay.off[k], lay.off[k] + int(np.prod(v))) for k, v in tab.items())
+    assert all(a % 8 == 0 for a, _ in spans)
+    assert all(spans[i][1] <= spans[i + 1][0] for i in range(len(spans) - 1))  # disjoint
+    assert spans[-1][1] <= lay.n
+    # adaLN weights are stacked densely: one GEMM produces every modulation vector
+    assert lay.ada_b - lay.ada_w == sp.n_mod * sp.D
+    # DP slabs tile the arena exactly
+    cov = np.zeros(lay.n, dtype=np.int32)
+    for lo, hi in lay.slabs.values():
+        cov[lo:hi] += 1
+    assert (cov == 1).all()
+    if model == 'DiT-XL/2' and R == 32:
+        assert sum(int(np.prod(v)) for v in tab.values()) == 730_115_216
+
+
+def test_module_surface_cpu():
+    import maskdit_amd as M
+    net = M.Precond_models['edm'](img_resolution=32, img_channels=4, num_classes=1000, model_type='DiT-S/2',
+                                  use_decoder=True, mae_loss_coef=0.1, pad_cls_token=False)
+    cfg = O.make_cfg('DiT-S/2')
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == O.param_shapes(cfg)
+    P = O.init_params(cfg)
+    assert torch.allclose(net.model.pos_embed, P['model.pos_embed']) and torch.allclose(net.model.decoder_pos_embed, P['model.decoder_pos_embed'])
+    assert not net.model.pos_embed.requires_grad and net.model.mask_token.requires_grad
+    assert net.model.patch_size == 2 and net.model.out_channels == 4 and net.model.extras == 0 and net.model.cls_token is None
+    assert (net.img_resolution, net.img_channels, net.num_classes, net.sigma_min, net.sigma_max) == (32, 4, 1000, 0, float('inf'))
+    assert float(net.model.final_layer.linear.weight.abs().max()) == 0.0  # adaLN-zero style init (maskdit.py:380-383)
+    net.load_state_dict(P, strict=True)
+    with pytest.raises(M.MaskDiTLibError):
+        net(torch.zeros(1, 4, 32, 32), torch.ones(1))
+    with pytest.raises(M.MaskDiTLibError):
+        M.Losses['edm']()(net, torch.zeros(1, 4, 32, 32), torch.zeros(1, 1000))
+    with pytest.raises(NotImplementedError):
+        M.Precond_models['edm'](img_resolution=32, img_channels=4, num_classes=1000, model_type='DiT-S/2', pad_cls_token=True)
+
+
+def test_schedules_and_config():
+    from maskdit_amd.schedule import get_mask_ratio_fn, get_one_hot, load_config, lr_rampup_factor
+    xs = np.linspace(0, 1, 7)
+    for k in range(2, 7):  # train_utils/helper.py:10-19
+        f = get_mask_ratio_fn(f'cosine{k}', 0.75, 0.25)
+        np.testing.assert_allclose([f(x) for x in xs], 0.5 * np.cos(np.pi * xs / 2) ** k + 0.25, rtol=1e-12)
+    np.testing.assert_allclose([get_mask_ratio_fn('exp', 0.5, 0.1)(x) for x in xs], 0.4 * np.exp(-7 * xs) + 0.1)
+    np.testing.assert_allclose([get_mask_ratio_fn('linear', 0.5, 0.1)(x) for x in xs], 0.4 * xs + 0.1)
+    assert get_mask_ratio_fn('constant', 0.5)(0.3) == 0.5
+    with pytest.raises(ValueError):
+        get_mask_ratio_fn('cos4')  # the typo in configs/finetune/*.yaml of the reference stays an error
+    assert lr_rampup_factor(0, 1024, 0) == 0.0 and lr_rampup_factor(1, 1024, 0) == 1.0
+    assert math.isclose(lr_rampup_factor(10, 1024, 100), 10 * 1024 / 100e3)
+    oh = get_one_hot(torch.tensor([3, 0]), 5)
+    assert oh.tolist() == [[0, 0, 0, 1, 0], [1, 0, 0, 0, 0]]
+    cfg = load_config(os.path.join(ROOT, 'configs', 'xl2-256-synthetic.yaml'))
+    assert cfg.model.model_type == 'DiT-XL/2' and cfg.train.batchsize == 128 and cfg.model.mae_loss_coef == 0.1
+
+
+def test_gemm_nt8_wait_counts():
+    """The compile-time vmcnt operands of gemm_nt8 (maskdit_amd/csrc/gemm_nt8.hip: wait_count) restated:
+    simulate the steady-state issue sequence and check that the awaited load is exactly the oldest of
+    the W+1 most recent ones (loads retire in order)."""
+    def c_issue(p, nf):
+        return 1 + (p < nf)
+
+    def wait_count(p, nf):
+        w = 1 if ((p + 2) & 3) < nf else 0
+        for d in range(5, -1, -1):
+            w += c_issue((p - d) % 4, nf)
+        if p == 2:
+            w = min(w, (4 - nf) + c_issue(0, nf) + c_issue(1, nf) + c_issue(2, nf))
+        return w
+
+    for nf in (2, 3, 4):
+        seq = []  # (kind, tile, slot)
+        need_at = {}
+        for g in range(0, 40):
+            t, p = divmod(g, 4)
+            seq.append(('A', t + 2, p))
+            if p < nf:
+                seq.append(('B', t + 2, p))
+            if g < 12:
+                continue
+            # end of phase g: next phase prefetches A slot (p+2)&3 of tile t (p<=1) or t+1, and at p==2 all B of t+1
+            tile = t if p <= 1 else t + 1
+            awaited = [('A', tile, (p + 2) & 3)] + ([('B', t + 1, j) for j in range(nf)] if p == 2 else [])
+            w = wait_count(p, nf)
+            landed = set(seq[:len(seq) - w])
+            assert all(a in landed for a in awaited), (nf, g, w)
+            # and the wait is not needlessly strict: with W+1 outstanding some awaited load would be in flight
+            assert any(a not in set(seq[:len(seq) - w - 1]) for a in awaited), (nf, g, w)

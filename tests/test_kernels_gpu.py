@@ -114,6 +114,75 @@ def test_gemm_tn(M, N1, N2, splits):
     close(Cc, ref, 1e-5, f'gemm_tn {M}x{N1}x{N2}')
 
 
+@pytest.mark.parametrize('M,N1,N2', [(8192, 1152, 384), (8192, 384, 1152), (8320, 640, 512), (16384, 512, 2048)])
+def test_gemm_tn8_pipelined(M, N1, N2):
+    """Large weight-gradient shapes take the 256x128 ring-pipelined kernel (gemm_tn8.hip): ragged
+    256-wide tiles (1152 = 4.5 x 256), the operand-swapped store path (N2 takes the 256 role) and a
+    slot count that is not a multiple of the ring length; cross-checked against the 128x128 kernel."""
+    torch.manual_seed(21)
+    A = bf(torch.randn(M, N1, device=DEV))
+    Bm = bf(torch.randn(M, N2, device=DEV))
+    ref = A.float().t() @ Bm.float() + 1.0
+    got = {}
+    for v in (1, 0):
+        _lib.lib().mdt_set_tuning(b'gemm_tn_variant', v)
+        Cc = torch.ones(N1, N2, device=DEV)
+        ops.gemm_tn(A, Bm, Cc)
+        got[v] = Cc
+    _lib.lib().mdt_set_tuning(b'gemm_tn_variant', 0)
+    close(got[0], ref, 1e-5, f'gemm_tn8 {M}x{N1}x{N2}')
+    close(got[0], got[1], 1e-5, 'gemm_tn8 vs 128x128 kernel')
+    # asymmetric operand: A^T picks rows of B (detects transposed / permuted stores)
+    A2 = torch.zeros(M, N1, device=DEV)
+    A2[torch.arange(N1), torch.arange(N1)] = 1.0
+    B2 = bf(torch.arange(M, device=DEV)[:, None] * 0.25 + torch.arange(N2, device=DEV)[None, :] * 0.001)
+    Cc = torch.zeros(N1, N2, device=DEV)
+    ops.gemm_tn(bf(A2), B2, Cc)
+    assert torch.equal(Cc, B2[:N1].float())
+
+
+@pytest.mark.parametrize('M,N,K', [(256, 256, 128), (512, 384, 256), (1024, 640, 384), (2048, 1152, 1152), (768, 2048, 512)])
+def test_gemm_nt8_pipelined(M, N, K):
+    """256-row phase-pipelined NT kernel (gemm_nt8.hip) forced on small problems: all three tile
+    widths (NF = 4, 3, 2), 2 .. 18 K-tiles, every fused epilogue; must agree bit for bit with the
+    128x128 kernel (same MFMA order) and with an fp32 matmul within bf16 rounding."""
+    torch.manual_seed(22)
+    L = 128
+    A = bf(torch.randn(M, K, device=DEV) * 0.5)
+    W = bf(torch.randn(N, K, device=DEV) * 0.05)
+    b = torch.randn(N, device=DEV) * 0.1
+    res = torch.randn(M, N, device=DEV)
+    gate = torch.randn(M // L, 2 * N, device=DEV)
+    aux = bf(torch.randn(M, N, device=DEV))
+    cases = [dict(bias=b, epi=ops.EPI_BF16), dict(bias=b, epi=ops.EPI_F32), dict(bias=b, epi=ops.EPI_GELU),
+             dict(bias=b, epi=ops.EPI_SILU),
+             dict(bias=b, epi=ops.EPI_GATE_RES, res=res, gate=gate[:, N:], gate_ld=2 * N, rows_per_sample=L),
+             dict(bias=None, epi=ops.EPI_DGELU, aux=aux), dict(bias=None, epi=ops.EPI_DSILU, aux=aux)]
+    lib = _lib.lib()
+    try:
+        for kw in cases:
+            got = {}
+            for v in (1, 2):
+                lib.mdt_set_tuning(b'gemm_nt_variant', v)
+                got[v] = ops.gemm_nt(A, W, **kw)
+            for x, y in zip(got[1], got[2]):
+                if x is not None:
+                    assert torch.equal(x, y), f'nt8 differs from the 128x128 kernel (epi {kw["epi"]})'
+        lib.mdt_set_tuning(b'gemm_nt_variant', 2)
+        _, _, outf = ops.gemm_nt(A, W, b, ops.EPI_F32)
+        close(outf, A.float() @ W.float().t() + b, 1e-5, f'gemm_nt8 {M}x{N}x{K}')
+        # A = I with an asymmetric weight: catches transposed / permuted tiles
+        if K == M or True:
+            Ai = torch.zeros(M, K, device=DEV)
+            Ai[torch.arange(min(M, K)), torch.arange(min(M, K))] = 1.0
+            Wa = bf(torch.arange(N, device=DEV)[:, None] * 0.5 + torch.arange(K, device=DEV)[None, :] * 0.001)
+            _, _, o2 = ops.gemm_nt(bf(Ai), Wa, None, ops.EPI_F32)
+            r = min(M, K)
+            assert torch.equal(o2[:r], Wa.float().t()[:r])
+    finally:
+        lib.mdt_set_tuning(b'gemm_nt_variant', 0)
+
+
 def test_gemm_tn_asymmetric_and_edges():
     M = 64
     A = torch.zeros(M, 128, device=DEV)

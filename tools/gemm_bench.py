@@ -24,6 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--rounds', type=int, default=3)
+    ap.add_argument('--tn', action='store_true')
     args = ap.parse_args()
     L = _lib.lib()
     dev = 'cuda'
@@ -81,5 +82,48 @@ def main():
     L.mdt_set_tuning(b'gemm_nt_variant', 0)
 
 
-if __name__ == '__main__':
+if __name__ == '__main__' and '--tn' not in sys.argv:
     main()
+
+
+def tn_main(iters=10, rounds=3):
+    """Weight-gradient GEMM C[N1,N2] += A[M,N1]^T B[M,N2]: variant 1 (128x128) vs auto (tn8)."""
+    L = _lib.lib()
+    dev = 'cuda'
+    ev = [C.c_void_p() for _ in range(2)]
+    for e in ev:
+        L.mdt_event_create(C.byref(e))
+    st = torch.cuda.current_stream().cuda_stream
+    shapes = [(4096, 512, 512, 'minimal'), (8192, 1152, 384, 'ragged x'), (4096, 384, 1152, 'swap ragged'), (4160, 640, 512, 'odd slots'),
+              (32768, 1152, 1152, 'XL proj'), (32768, 3456, 1152, 'XL qkv'), (32768, 4608, 1152, 'XL fc1'),
+              (32768, 1152, 4608, 'XL fc2'), (65536, 512, 512, 'dec proj'), (65536, 1536, 512, 'dec qkv'),
+              (65536, 2048, 512, 'dec fc1'), (65536, 512, 2048, 'dec fc2')]
+    print(f'{"TN shape (M,N1,N2)":34s} {"v1 TF/s":>9s} {"tn8 TF/s":>9s} {"ratio":>6s}  tn8-v1 relerr  tn8-ref relerr')
+    for M, N1, N2, tag in shapes:
+        A = (torch.rand(M, N1, device=dev) * 2 - 1).to(torch.bfloat16)
+        B = (torch.rand(M, N2, device=dev) * 2 - 1).to(torch.bfloat16)
+        outs, times = {}, {1: [], 0: []}
+        for r in range(rounds):
+            for v in (1, 0):
+                L.mdt_set_tuning(b'gemm_tn_variant', v)
+                Cc = torch.zeros(N1, N2, device=dev)
+                ops.gemm_tn(A, B, Cc)
+                outs[v] = Cc.clone()
+                L.mdt_event_record(ev[0], st)
+                for _ in range(iters):
+                    ops.gemm_tn(A, B, Cc)
+                L.mdt_event_record(ev[1], st)
+                ms = C.c_float()
+                L.mdt_event_elapsed_ms(ev[0], ev[1], C.byref(ms))
+                times[v].append(ms.value / iters)
+        tf = {v: 2.0 * M * N1 * N2 / (sorted(times[v])[len(times[v]) // 2] * 1e-3) / 1e12 for v in (1, 0)}
+        ref = A.float().t() @ B.float()
+        sc = ref.abs().max()
+        d = ((outs[0] - outs[1]).abs().max() / sc).item()
+        rel = ((outs[0] - ref).abs().max() / sc).item()
+        print(f'{str((M, N1, N2)) + " " + tag:34s} {tf[1]:9.1f} {tf[0]:9.1f} {tf[0] / tf[1]:6.2f}  {d:12.3e}   {rel:10.3e}', flush=True)
+    L.mdt_set_tuning(b'gemm_tn_variant', 0)
+
+
+if __name__ == '__main__' and '--tn' in sys.argv:
+    tn_main()
