@@ -266,7 +266,9 @@ extern "C" int mdt_gemm_nt(const mdt_gemm_nt_args* a, mdt_stream_t stream) {
   if (variant != 1 && a->M % 256 == 0 && a->K % 128 == 0) {
     int nf = (a->N % 256 == 0) ? 4 : (a->N % 192 == 0) ? 3 : 2;
     long tiles8 = (long)(a->M / 256) * (a->N / (64 * nf));
+    if (mdt_get_tuning_int(MDT_TUNE_NT8_SKIP_EPILOGUE)) p.epi |= 0x100;
     if (variant == 2 || tiles8 >= 192) return launch_gemm_nt8(p, nf, (hipStream_t)stream);
+    p.epi &= 0xff;
   }
   int tiles = cdiv(a->M, BM) * (a->N / BN);
   hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, p);

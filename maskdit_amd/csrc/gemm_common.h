@@ -75,22 +75,54 @@ template <int CW> __device__ __forceinline__ void load_bf16_row(const bf16* a, f
 }
 
 // Fused epilogue on CW consecutive columns [n, n+CW) of output row m (accumulators in v[]).
-// Epilogue semantics: include/maskdit_hip.h (enum mdt_epilogue).
-template <int CW> __device__ __forceinline__ void nt_epilogue_row(const NTParams& p, int m, int n, float* v) {
-  if (m >= p.M) return;
-  if (p.bias) {
+// Epilogue semantics: include/maskdit_hip.h (enum mdt_epilogue).  Split in two so that a kernel
+// can issue the global loads of row i+1 (residual, gate, saved pre-activation) before it does the
+// arithmetic and stores of row i:
+//   nt_epilogue_prefetch : loads only       nt_epilogue_finish : arithmetic + stores
+template <int CW> struct NtPre {
+  float ra[CW];    // residual row (GATE_RES) or saved pre-activation (DGELU / DSILU): never both
+  float gate[CW];
+};
+
+template <int CW> __device__ __forceinline__ void nt_load_bias(const NTParams& p, int n, float* bias) {
+#pragma unroll
+  for (int q = 0; q < CW; q += 4) {
+    f32x4 b = p.bias ? *(const f32x4*)(p.bias + n + q) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    bias[q] = b[0]; bias[q + 1] = b[1]; bias[q + 2] = b[2]; bias[q + 3] = b[3];
+  }
+}
+
+template <int CW> __device__ __forceinline__ void nt_epilogue_prefetch(const NTParams& p, int m, int n, NtPre<CW>& d) {
+  // every field is written on every path so that the struct stays in registers (no stack object)
+#pragma unroll
+  for (int q = 0; q < CW; ++q) { d.ra[q] = 0.f; d.gate[q] = 0.f; }
+  const int epi = p.epi;
+  if (m >= p.M) {
+  } else if (epi == MDT_EPI_GATE_RES) {
+    const float* g = p.gate + (long)(m / p.rows_per_sample) * p.gate_ld + n;
+    const float* rs = p.res + (long)m * p.ldres + n;
 #pragma unroll
     for (int q = 0; q < CW; q += 4) {
-      f32x4 b = *(const f32x4*)(p.bias + n + q);
-      v[q] += b[0]; v[q + 1] += b[1]; v[q + 2] += b[2]; v[q + 3] += b[3];
+      f32x4 gv = *(const f32x4*)(g + q);
+      f32x4 rv = *(const f32x4*)(rs + q);
+      d.gate[q] = gv[0]; d.gate[q + 1] = gv[1]; d.gate[q + 2] = gv[2]; d.gate[q + 3] = gv[3];
+      d.ra[q] = rv[0]; d.ra[q + 1] = rv[1]; d.ra[q + 2] = rv[2]; d.ra[q + 3] = rv[3];
     }
+  } else if (epi == MDT_EPI_DGELU || epi == MDT_EPI_DSILU) {
+    load_bf16_row<CW>(p.aux + (long)m * p.ldaux + n, d.ra);
   }
+}
+
+template <int CW>
+__device__ __forceinline__ void nt_epilogue_finish(const NTParams& p, int m, int n, float* v, const float* bias,
+                                                   const NtPre<CW>& d) {
+  if (m >= p.M) return;
+#pragma unroll
+  for (int q = 0; q < CW; ++q) v[q] += bias[q];
   const int epi = p.epi;
   if (epi == MDT_EPI_DGELU || epi == MDT_EPI_DSILU) {
-    float h[CW];
-    load_bf16_row<CW>(p.aux + (long)m * p.ldaux + n, h);
 #pragma unroll
-    for (int q = 0; q < CW; ++q) v[q] *= (epi == MDT_EPI_DGELU) ? gelu_tanh_grad(h[q]) : silu_grad(h[q]);
+    for (int q = 0; q < CW; ++q) v[q] *= (epi == MDT_EPI_DGELU) ? gelu_tanh_grad(d.ra[q]) : silu_grad(d.ra[q]);
   }
   if (epi == MDT_EPI_F32) {
     float* o = p.outf + (long)m * p.ldof + n;
@@ -108,19 +140,23 @@ template <int CW> __device__ __forceinline__ void nt_epilogue_row(const NTParams
     for (int q = 0; q < CW; ++q) a[q] = (epi == MDT_EPI_GELU) ? gelu_tanh(y[q]) : silu(y[q]);
     store_bf16_row<CW>(p.out2 + (long)m * p.ldo2 + n, a);
   } else if (epi == MDT_EPI_GATE_RES) {
-    const float* g = p.gate + (long)(m / p.rows_per_sample) * p.gate_ld + n;
-    const float* rs = p.res + (long)m * p.ldres + n;
     float* o = p.outf + (long)m * p.ldof + n;
 #pragma unroll
     for (int q = 0; q < CW; q += 4) {
-      f32x4 gv = *(const f32x4*)(g + q);
-      f32x4 rv = *(const f32x4*)(rs + q);
       f32x4 ov;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) ov[e] = rv[e] + gv[e] * y[q + e];
+      for (int e = 0; e < 4; ++e) ov[e] = d.ra[q + e] + d.gate[q + e] * y[q + e];
       *(f32x4*)(o + q) = ov;
     }
   }
+}
+
+template <int CW> __device__ __forceinline__ void nt_epilogue_row(const NTParams& p, int m, int n, float* v) {
+  float bias[CW];
+  NtPre<CW> d;
+  nt_load_bias<CW>(p, n, bias);
+  nt_epilogue_prefetch<CW>(p, m, n, d);
+  nt_epilogue_finish<CW>(p, m, n, v, bias, d);
 }
 
 int launch_gemm_nt8(const NTParams& p, int nf, hipStream_t stream);

@@ -15,7 +15,11 @@
 //     W_p = number of loads issued after the one that the NEXT phase's reads depend on (loads
 //     retire in order), computed at compile time -- never 0 until the last two K-tiles;
 //   * XOR-swizzled LDS image through the *source* address (LDS-DMA destinations are lane-linear),
-//     conflict-free ds_read_b128 fragment reads; XCD-aware tile order.
+//     conflict-free ds_read_b128 fragment reads; XCD-aware tile order;
+//   * PERSISTENT: one workgroup per CU walks the tile list; when a tile's K loop ends, the first
+//     two K-tiles of the workgroup's NEXT output tile are put in flight before the epilogue runs
+//     (the epilogue stages accumulators through a dedicated LDS region), so the operand fetch
+//     latency and the drain of the epilogue's global stores overlap instead of adding up.
 //
 // Requirements (checked by the dispatcher in gemm.hip): M % 256 == 0, N % (64*NF) == 0,
 // K % 128 == 0.  Everything else runs the 128x128 kernel in gemm.hip.
@@ -46,6 +50,19 @@ constexpr int wait_count(int p, int NF) {
 // | vmcnt_hi[15:14]) so that hipcc's own waitcnt bookkeeping sees the LDS reads as retired and
 // does not re-wait (lgkmcnt(0)) in front of the next phase's MFMAs; the empty asm statements pin
 // the memory-operation order around it.
+// vmcnt operand at the end of phase d (0..7) of the LAST pair of K-tiles, where nothing is issued any
+// more: the steady-state count minus the loads those phases would have issued
+constexpr int drain_count(int d, int NF) {
+  if (d >= 6) return 0;  // nothing left to fetch: only LDS reads remain
+  int w = (((d + 2) & 3) < NF) ? 1 : 0;                          // B issued right after the awaited A load (phase -6+d)
+  for (int e = d - 5; e < 0; ++e) w += c_issue(((e % 4) + 4) % 4, NF);  // steady phases after it
+  if (d == 2) {
+    int wb = 4 - NF;  // A loads issued after the last B instruction of the final K-tile
+    if (wb < w) w = wb;
+  }
+  return w;
+}
+
 template <int N> __device__ __forceinline__ void wait_vm_lgkm() {
   static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
   asm volatile("" ::: "memory");
@@ -60,7 +77,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(NTParams p) {
   constexpr int BN8 = 64 * NF;
   constexpr int A_BYTES = 256 * 128;
   constexpr int STAGE = A_BYTES + BN8 * 128;
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  // epilogue staging (wave-private 16-row bands, fp32): padded pitch where LDS allows it; the
+  // 256x256 tile uses the last 32 KiB of the 160 KiB LDS unpadded
+  constexpr int WN = 16 * NF;
+  constexpr int SP = (NF == 4) ? WN : WN + 4;
+  constexpr int STG_BYTES = 8 * 16 * SP * 4;
+  static_assert(2 * STAGE + STG_BYTES <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + STG_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -68,16 +91,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(NTParams p) {
   const int wr = wave >> 2, wc = wave & 3;
 
   const int tiles_m = p.M >> 8, tiles_n = p.N / BN8;
+  const int ntiles = tiles_m * tiles_n;
+  int vt = blockIdx.x;  // virtual tile id of this workgroup's current tile (stride gridDim.x)
   int tm, tn;
-  tile_coords(xcd_remap(blockIdx.x, gridDim.x), tiles_m, tiles_n, tm, tn);
-  const int m0 = tm << 8, n0 = tn * BN8;
+  tile_coords(xcd_remap(vt, ntiles), tiles_m, tiles_n, tm, tn);
+  int m0 = tm << 8, n0 = tn * BN8;
 
   // ---- LDS-DMA addressing.  One wave-instruction = 8 tile rows x 128 B; lane -> (row lane/8,
   // LDS chunk lane%8); the global chunk is XOR-swizzled with (row & 7) = lane/8.
   const int lr = lane >> 3, gch = (lane & 7) ^ lr;
   // A slot q: wave w covers tile rows (w>>2)*128 + 32q + 8(w&3) .. +7
   const int a_row0 = (wave >> 2) * 128 + 8 * (wave & 3);
-  const bf16* a_src = p.A + (long)(m0 + a_row0 + lr) * p.lda + gch * 8;
+  const bf16* a_src = p.A + (long)(m0 + a_row0 + lr) * p.lda + gch * 8;  // re-pointed per tile
   const long a_qstride = 32L * p.lda;
   // B instruction j: wave w covers tile rows 64j + 8w .. +7
   const bf16* b_src = p.B + (long)(n0 + 8 * wave + lr) * p.ldb + gch * 8;
@@ -102,10 +127,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(NTParams p) {
   }
 
   f32x4 acc[8][NF];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // B fragments are double-buffered across K-tiles while the register file allows it (NF <= 3);
   // for NF = 4 the next tile's B replaces the current one inside phase 3, ks by ks.
@@ -115,12 +136,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(NTParams p) {
 
   const int nk = p.K >> 6;  // even, >= 2
 
-  // ---- prologue: K-tiles 0 and 1 in steady-state issue order
+  // ---- prologue of the first tile: K-tiles 0 and 1 in steady-state issue order
 #pragma unroll
   for (int ph = 0; ph < 4; ++ph) issue(0, 0, ph);
 #pragma unroll
   for (int ph = 0; ph < 4; ++ph) issue(1, 1, ph);
-  wait_vm_lgkm<4 + NF>();  // K-tile 0 landed (this wave's part)
+
+  for (;;) {  // persistent tile loop
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // the two K-tiles of this output tile were put in flight before the previous tile's epilogue
+  // (or just above): everything older -- including that epilogue's stores -- must have retired
+  wait_vm_lgkm<0>();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 #pragma unroll
@@ -166,7 +195,15 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(NTParams p) {
       }                                                                                               \
       __builtin_amdgcn_s_setprio(0);                                                                  \
       /* (4) publish: my share of the next phase's data has landed, my LDS reads have retired */      \
-      if (DRAIN) wait_vm_lgkm<0>();                                                                   \
+      if (DRAIN) {                                                                                    \
+        if (half == 0 && ph == 0) wait_vm_lgkm<drain_count(0, NF)>();                                 \
+        else if (half == 0 && ph == 1) wait_vm_lgkm<drain_count(1, NF)>();                            \
+        else if (half == 0 && ph == 2) wait_vm_lgkm<drain_count(2, NF)>();                            \
+        else if (half == 0 && ph == 3) wait_vm_lgkm<drain_count(3, NF)>();                            \
+        else if (half == 1 && ph == 0) wait_vm_lgkm<drain_count(4, NF)>();                            \
+        else if (half == 1 && ph == 1) wait_vm_lgkm<drain_count(5, NF)>();                            \
+        else wait_vm_lgkm<0>();                                                                       \
+      }                                                                                               \
       else if (ph == 0) wait_vm_lgkm<wait_count(0, NF)>();                                            \
       else if (ph == 1) wait_vm_lgkm<wait_count(1, NF)>();                                            \
       else if (ph == 2) wait_vm_lgkm<wait_count(2, NF)>();                                            \
@@ -181,38 +218,88 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(NTParams p) {
   { PAIR_BODY(true) }
 #undef PAIR_BODY
 
-  // ---- epilogue: restage each 16-row fragment band through LDS (all stages are free now) so
+  // ---- next tile: put its first two K-tiles in flight (every LDS read of this tile retired
+  // before the last barrier), then run this tile's epilogue underneath them
+  const int em0 = m0, en0 = n0;
+  vt += gridDim.x;
+  const bool more = vt < ntiles;
+  if (more) {
+    tile_coords(xcd_remap(vt, ntiles), tiles_m, tiles_n, tm, tn);
+    m0 = tm << 8;
+    n0 = tn * BN8;
+    a_src = p.A + (long)(m0 + a_row0 + lr) * p.lda + gch * 8;
+    b_src = p.B + (long)(n0 + 8 * wave + lr) * p.ldb + gch * 8;
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) issue(0, 0, ph);
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) issue(1, 1, ph);
+  }
+
+  // ---- epilogue: restage each 16-row fragment band through the wave-private staging region so
   // that a lane owns 4*NF consecutive columns of one row, then run the shared fused epilogue.
-  constexpr int WN = 16 * NF;       // wave tile width
-  constexpr int SP = WN + 4;        // padded row pitch (floats)
-  float* stg = (float*)(smem + wave * (16 * SP * 4));
+  float* stg = (float*)(smem + 2 * STAGE + wave * (16 * SP * 4));
   const int er = lane >> 2, ec = (lane & 3) * (4 * NF);
-  const int n = n0 + wc * WN + ec;
+  const int n = en0 + wc * WN + ec;
+  if (p.epi & 0x100) {  // benchmarking aid (mdt_set_tuning "nt8_skip_epilogue"): main loop only
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < NF; ++j) asm volatile("" ::"v"(acc[i][j]));
+    if (!more) break;
+    continue;
+  }
+  // software pipeline over the 8 bands: the LDS round trip and the row-dependent global loads of
+  // band i+1 are issued before the arithmetic + stores of band i
+  float bias[4 * NF];
+  nt_load_bias<4 * NF>(p, n, bias);
+  NtPre<4 * NF> pre[2];
+  nt_epilogue_prefetch<4 * NF>(p, em0 + wr * 128 + er, n, pre[0]);
+#pragma unroll
+  for (int j = 0; j < NF; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) stg[(fg * 4 + r) * SP + j * 16 + fr] = acc[0][j][r];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-#pragma unroll
-    for (int j = 0; j < NF; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) stg[(fg * 4 + r) * SP + j * 16 + fr] = acc[i][j][r];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // wave-private staging: no barrier needed
     float v[4 * NF];
 #pragma unroll
     for (int q = 0; q < NF; ++q) {
       f32x4 t = *(const f32x4*)(stg + er * SP + ec + q * 4);
       v[q * 4 + 0] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const int m = m0 + wr * 128 + i * 16 + er;
-    nt_epilogue_row<4 * NF>(p, m, n, v);
+    if (i < 7) {
+      // LDS executes a wave's operations in order: these writes cannot overtake the reads above
+#pragma unroll
+      for (int j = 0; j < NF; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stg[(fg * 4 + r) * SP + j * 16 + fr] = acc[i + 1][j][r];
+      nt_epilogue_prefetch<4 * NF>(p, em0 + wr * 128 + (i + 1) * 16 + er, n, pre[(i + 1) & 1]);
+    }
+    const int m = em0 + wr * 128 + i * 16 + er;
+    nt_epilogue_finish<4 * NF>(p, m, n, v, bias, pre[i & 1]);
   }
+  if (!more) break;
+  }  // persistent tile loop
 }
 
 template __global__ void gemm_nt8_kernel<2>(NTParams);
 template __global__ void gemm_nt8_kernel<3>(NTParams);
 template __global__ void gemm_nt8_kernel<4>(NTParams);
 
+static int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
 int launch_gemm_nt8(const NTParams& p, int nf, hipStream_t stream) {
-  const int tiles = (p.M >> 8) * (p.N / (64 * nf));
+  const int ntiles = (p.M >> 8) * (p.N / (64 * nf));
+  const int cus = num_cus();
+  const int tiles = ntiles < cus ? ntiles : cus;  // one persistent workgroup per CU
   switch (nf) {
     case 2: hipLaunchKernelGGL(gemm_nt8_kernel<2>, dim3(tiles), dim3(512), 0, stream, p); break;
     case 3: hipLaunchKernelGGL(gemm_nt8_kernel<3>, dim3(tiles), dim3(512), 0, stream, p); break;

@@ -110,3 +110,37 @@ def test_gemm_nt8_wait_counts():
             assert all(a in landed for a in awaited), (nf, g, w)
             # and the wait is not needlessly strict: with W+1 outstanding some awaited load would be in flight
             assert any(a not in set(seq[:len(seq) - w - 1]) for a in awaited), (nf, g, w)
+
+
+def test_gemm_nt8_drain_counts():
+    """Tail of the same pipeline (maskdit_amd/csrc/gemm_nt8.hip: drain_count): in the last pair of
+    K-tiles nothing is issued any more; the operand must still cover the load the next phase needs."""
+    def c_issue(p, nf):
+        return 1 + (p < nf)
+
+    def drain_count(d, nf):
+        if d >= 6:
+            return 0
+        w = 1 if ((d + 2) & 3) < nf else 0
+        for e in range(d - 5, 0):
+            w += c_issue(e % 4, nf)
+        if d == 2:
+            w = min(w, 4 - nf)
+        return w
+
+    for nf in (2, 3, 4):
+        seq = []
+        T = 6  # K-tiles; the last pair (tiles 4, 5) is the drain body
+        for g in range(0, 4 * (T - 2)):  # steady phases issue tile t+2
+            t, p = divmod(g, 4)
+            seq.append(('A', t + 2, p))
+            if p < nf:
+                seq.append(('B', t + 2, p))
+        for d in range(6):
+            t, p = divmod(4 * (T - 2) + d, 4)
+            tile = t if p <= 1 else t + 1
+            awaited = [('A', tile, (p + 2) & 3)] + ([('B', t + 1, j) for j in range(nf)] if p == 2 else [])
+            awaited = [a for a in awaited if a[1] < T]
+            w = drain_count(d, nf)
+            landed = set(seq[:len(seq) - w]) if w else set(seq)
+            assert all(a in landed for a in awaited), (nf, d, w)

@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--rounds', type=int, default=3)
     ap.add_argument('--tn', action='store_true')
+    ap.add_argument('--ablate', action='store_true')
     args = ap.parse_args()
     L = _lib.lib()
     dev = 'cuda'
@@ -82,7 +83,7 @@ def main():
     L.mdt_set_tuning(b'gemm_nt_variant', 0)
 
 
-if __name__ == '__main__' and '--tn' not in sys.argv:
+if __name__ == '__main__' and '--tn' not in sys.argv and '--ablate' not in sys.argv:
     main()
 
 
@@ -127,3 +128,38 @@ def tn_main(iters=10, rounds=3):
 
 if __name__ == '__main__' and '--tn' in sys.argv:
     tn_main()
+
+
+def ablate_main(iters=10):
+    """nt8: full kernel vs main loop only (epilogue skipped) on the XL shapes -> per-tile fixed cost."""
+    L = _lib.lib()
+    dev = 'cuda'
+    ev = [C.c_void_p() for _ in range(2)]
+    for e in ev:
+        L.mdt_event_create(C.byref(e))
+    st = torch.cuda.current_stream().cuda_stream
+    L.mdt_set_tuning(b'gemm_nt_variant', 2)
+    print(f'{"shape":30s} {"full TF/s":>10s} {"no-epi TF/s":>12s} {"full us":>9s} {"no-epi us":>10s}')
+    for M, N, K in [(32768, 1152, 1152), (32768, 3456, 1152), (32768, 4608, 1152), (32768, 1152, 4608), (32768, 1152, 2304), (32768, 1152, 256)]:
+        A = (torch.rand(M, K, device=dev) * 2 - 1).to(torch.bfloat16)
+        W = (torch.rand(N, K, device=dev) * 2 - 1).to(torch.bfloat16)
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        res = {}
+        for skip in (0, 1, 0, 1):
+            L.mdt_set_tuning(b'nt8_skip_epilogue', skip)
+            ops.gemm_nt(A, W, None, ops.EPI_BF16, out=out)
+            L.mdt_event_record(ev[0], st)
+            for _ in range(iters):
+                ops.gemm_nt(A, W, None, ops.EPI_BF16, out=out)
+            L.mdt_event_record(ev[1], st)
+            ms = C.c_float()
+            L.mdt_event_elapsed_ms(ev[0], ev[1], C.byref(ms))
+            res[skip] = min(res.get(skip, 1e9), ms.value / iters)
+        f = 2.0 * M * N * K
+        print(f'{str((M, N, K)):30s} {f / res[0] / 1e9:10.1f} {f / res[1] / 1e9:12.1f} {res[0] * 1e3:9.1f} {res[1] * 1e3:10.1f}', flush=True)
+    L.mdt_set_tuning(b'nt8_skip_epilogue', 0)
+    L.mdt_set_tuning(b'gemm_nt_variant', 0)
+
+
+if __name__ == '__main__' and '--ablate' in sys.argv:
+    ablate_main()
