@@ -48,6 +48,9 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip the per-launch HIP events (roofline = null)')
     ap.add_argument('--cpu-batch', type=int, default=16)
+    ap.add_argument('--no-sampler', action='store_true', help='skip the EDM sampler leg (BASELINE configs[4])')
+    ap.add_argument('--sampler-batch', type=int, default=64)
+    ap.add_argument('--sampler-steps', type=int, default=50)
     return ap.parse_args()
 
 
@@ -244,7 +247,7 @@ def main():
         n, tot_ms, tot_fl = timer.summarise()
         if n and tot_ms > 0:
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
-            roof = {'bound': 'mfma', 'kernel': 'gemm_nt_kernel', 'achieved': round(ach, 1), 'peak': MFMA_BF16_PEAK_TFLOPS,
+            roof = {'bound': 'mfma', 'kernel': 'gemm_nt8_kernel (all mdt_gemm_nt launches)', 'achieved': round(ach, 1), 'peak': MFMA_BF16_PEAK_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': round(ach / MFMA_BF16_PEAK_TFLOPS, 4), 'traffic': None,
                     'launches': n, 'avg_launch_us': round(tot_ms * 1e3 / n, 2),
                     'avg_flops_per_launch': round(tot_fl / n / 1e9, 3), 'flops_unit': 'GFLOP',
@@ -255,6 +258,32 @@ def main():
                     roof['traffic'] = json.load(open(pmc)).get('hbm_bytes_per_launch')
                 except Exception:
                     pass
+
+    # ---- EDM sampler leg (BASELINE configs[4]): XL/2, 50 Heun steps (99 network evaluations of the
+    # CFG-doubled batch), cfg_scale 1.5, batch 64, hipGraph-captured; latents only (no VAE).  N = 1 only.
+    sampler = None
+    if rank == 0 and world == 1 and not args.no_sampler:
+        try:
+            net.engine().release_plans()  # training activations (~50 GB per plan) are not needed any more
+            torch.cuda.empty_cache()
+            ema.eval()
+            sb = args.sampler_batch
+            gs = torch.Generator(device=dev).manual_seed(7)
+            lat = torch.randn(sb, 4, R, R, device=dev, generator=gs)
+            lab = torch.eye(1000, device=dev)[torch.randint(0, 1000, (sb,), device=dev, generator=gs)]
+            M.edm_sampler(ema, lat, lab, cfg_scale=1.5, num_steps=4)  # capture + warm-up
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            z = M.edm_sampler(ema, lat, lab, cfg_scale=1.5, num_steps=args.sampler_steps)
+            torch.cuda.synchronize()
+            te = time.perf_counter() - ts
+            ok = bool(torch.isfinite(z).all())
+            evals = 2 * args.sampler_steps - 1
+            sampler = {'metric': f'EDM samples/sec {args.model} {args.sampler_steps}-step Heun cfg=1.5 bs={sb}', 'value': round(sb / te, 3),
+                       'unit': 'samples/s', 'seconds': round(te, 3), 'net_evals': evals, 'finite': ok, 'hipgraph': True,
+                       'model_tflops_per_s': round(sb * evals * 2 * 251.6e9 / te / 1e12, 1) if (args.model, R) == ('DiT-XL/2', 32) else None}
+        except Exception as e:
+            sampler = {'value': None, 'error': repr(e)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -277,7 +306,7 @@ def main():
                        'tokens_per_sample': (R // 2) ** 2, 'kept_tokens': (R // 2) ** 2 // 2, 'parallelism': f'dp{world}'},
             'model_tflops_per_s': round(value * 392.7e9 / 1e12, 1) if (args.model, R) == ('DiT-XL/2', 32) else None,
             'mean_loss': round(mean_loss, 5),
-            'roofline': roof, 'cpu_baseline': cpu,
+            'roofline': roof, 'sampler': sampler, 'cpu_baseline': cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

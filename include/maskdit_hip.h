@@ -60,6 +60,10 @@ typedef struct {
   const float* res; int ldres;
   const float* gate; int gate_ld; int rows_per_sample;
   const mdt_bf16* aux; int ldaux;
+  int k_splits; /* MDT_EPI_F32 only (out must be NULL): > 1 splits the contraction over that many
+                   workgroup groups; outf is cleared on the stream and accumulated with fp32 atomics.
+                   For skinny problems with a huge K (the stacked adaLN data-gradient:
+                   M = batch, N = D, K = all modulation outputs).  0/1 = off. */
 } mdt_gemm_nt_args;
 int mdt_gemm_nt(const mdt_gemm_nt_args* a, mdt_stream_t stream);
 

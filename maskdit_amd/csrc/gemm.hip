@@ -55,7 +55,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const int nk = p.K / BK;
+  // split-K (EPI_F32 accumulate): blockIdx.y selects a contiguous range of K-tiles
+  const int nk_total = p.K / BK;
+  const int nk_per = (nk_total + gridDim.y - 1) / gridDim.y;
+  const int kt0 = blockIdx.y * nk_per;
+  const int nk = min(nk_per, nk_total - kt0);
+  if (nk <= 0) return;
+  if (blockIdx.y > 0) p.bias = nullptr;
   // fragment read offsets (bytes) inside a stage: row r -> r*128 + ((kc ^ (r&7)) * 16)
   const int fr = lane & 15, fg = lane >> 4;
   int a_off[2], b_off[2];
@@ -70,8 +76,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTParams p) {
   {                                                                              \
     char* base = lds_wave + (st) * STAGE_BYTES;                                  \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                              \
-      glds16(a_src[i] + (long)(kt) * BK, base + i * 1024);                       \
-      glds16(b_src[i] + (long)(kt) * BK, base + 16384 + i * 1024);               \
+      glds16(a_src[i] + (long)(kt0 + (kt)) * BK, base + i * 1024);               \
+      glds16(b_src[i] + (long)(kt0 + (kt)) * BK, base + 16384 + i * 1024);       \
     }                                                                            \
   }
 
@@ -261,17 +267,38 @@ extern "C" int mdt_gemm_nt(const mdt_gemm_nt_args* a, mdt_stream_t stream) {
   p.outf = a->outf; p.ldof = a->ldof; p.res = a->res; p.ldres = a->ldres;
   p.gate = a->gate; p.gate_ld = a->gate_ld; p.rows_per_sample = a->rows_per_sample;
   p.aux = (const bf16*)a->aux; p.ldaux = a->ldaux;
-  // large aligned problems: 256 x (64*NF) tile, 8-wave phase-pipelined kernel (gemm_nt8.hip)
+  p.k_splits = 1;
+  // large aligned problems: phase-pipelined persistent kernels (gemm_nt8.hip).  variant 0 = auto:
+  // 256-row tiles, one 8-wave workgroup per CU (measured best inside the training step); M % 256 != 0
+  // falls to 128-row tiles with two 4-wave workgroups per CU (epilogue of one overlaps the K loop of
+  // the other; +2..5 % on K <= 1152 micro-benchmarks, -7 % at K >= 2048); 2 / 3 force either form.
   const int variant = mdt_get_tuning_int(MDT_TUNE_GEMM_NT_VARIANT);
-  if (variant != 1 && a->M % 256 == 0 && a->K % 128 == 0) {
-    int nf = (a->N % 256 == 0) ? 4 : (a->N % 192 == 0) ? 3 : 2;
-    long tiles8 = (long)(a->M / 256) * (a->N / (64 * nf));
+  if (variant != 1 && a->k_splits <= 1 && a->M % 128 == 0 && a->K % 128 == 0) {
     if (mdt_get_tuning_int(MDT_TUNE_NT8_SKIP_EPILOGUE)) p.epi |= 0x100;
-    if (variant == 2 || tiles8 >= 192) return launch_gemm_nt8(p, nf, (hipStream_t)stream);
+    const bool can8 = (a->M % 256 == 0);
+    if (can8 && (variant == 0 || variant == 2)) {
+      int nf = (a->N % 256 == 0) ? 4 : (a->N % 192 == 0) ? 3 : 2;
+      long tiles8 = (long)(a->M / 256) * (a->N / (64 * nf));
+      if (variant == 2 || tiles8 >= 192) return launch_gemm_nt8(p, nf, 2, (hipStream_t)stream);
+    }
+    int nf = (a->N % 192 == 0) ? 3 : 2;
+    long tiles4 = (long)(a->M / 128) * (a->N / (64 * nf));
+    if (variant == 3 || (variant == 0 && tiles4 >= 384)) return launch_gemm_nt8(p, nf, 1, (hipStream_t)stream);
     p.epi &= 0xff;
   }
   int tiles = cdiv(a->M, BM) * (a->N / BN);
-  hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, p);
+  int ks = 1;
+  if (a->k_splits > 1) {
+    MDT_REQUIRE(a->epi == MDT_EPI_F32 && a->out == nullptr, "gemm_nt: k_splits needs MDT_EPI_F32 without a bf16 output");
+    MDT_REQUIRE(a->ldof == a->N, "gemm_nt: k_splits needs a dense outf (ldof == N)");
+    ks = a->k_splits < a->K / BK ? a->k_splits : a->K / BK;
+    if (hipMemsetAsync(a->outf, 0, sizeof(float) * (size_t)a->M * a->N, (hipStream_t)stream) != hipSuccess) {
+      mdt_set_error("gemm_nt: clearing the split-K accumulator failed");
+      return MDT_ERR_LAUNCH;
+    }
+  }
+  p.k_splits = ks;
+  hipLaunchKernelGGL(gemm_nt_kernel, dim3(tiles, ks), dim3(256), 0, (hipStream_t)stream, p);
   return mdt_check_launch("gemm_nt");
 }
 

@@ -18,6 +18,7 @@ struct NTParams {
   const float* res; int ldres;
   const float* gate; int gate_ld; int rows_per_sample;
   const bf16* aux; int ldaux;
+  int k_splits;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -126,6 +127,11 @@ __device__ __forceinline__ void nt_epilogue_finish(const NTParams& p, int m, int
   }
   if (epi == MDT_EPI_F32) {
     float* o = p.outf + (long)m * p.ldof + n;
+    if (p.k_splits > 1) {  // split-K partial sum: accumulate (bias was added by split 0 only)
+#pragma unroll
+      for (int q = 0; q < CW; ++q) atomic_add_f32(o + q, v[q]);
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < CW; q += 4) *(f32x4*)(o + q) = (f32x4){v[q], v[q + 1], v[q + 2], v[q + 3]};
   }
@@ -159,6 +165,6 @@ template <int CW> __device__ __forceinline__ void nt_epilogue_row(const NTParams
   nt_epilogue_finish<CW>(p, m, n, v, bias, d);
 }
 
-int launch_gemm_nt8(const NTParams& p, int nf, hipStream_t stream);
+int launch_gemm_nt8(const NTParams& p, int nf, int wr, hipStream_t stream);
 int launch_gemm_tn8(const bf16* A, int lda, const bf16* B, int ldb, int M, int N1, int N2, float* C, int ldc,
                     hipStream_t stream);

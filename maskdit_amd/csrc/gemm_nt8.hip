@@ -29,18 +29,20 @@
 
 namespace {
 
-constexpr int c_issue(int p, int NF) { return 1 + (p < NF ? 1 : 0); }
+// loads issued per wave in phase p: one A slot + RPP B rounds while p < NF (RPP = 1 with 8 waves,
+// 2 with 4 waves: half as many waves share the same B tile)
+constexpr int c_issue(int p, int NF, int RPP) { return 1 + (p < NF ? RPP : 0); }
 
 // steady-state vmcnt operand at the end of phase p (see header)
-constexpr int wait_count(int p, int NF) {
+constexpr int wait_count(int p, int NF, int RPP) {
   // next phase (g+1) prefetches A slot (p+2)&3 [of the current or the next K-tile], issued at
   // phase g-6 whose phase index is (p+2)&3; the B instruction of that phase was issued after it.
-  int w = (((p + 2) & 3) < NF) ? 1 : 0;
-  for (int d = 5; d >= 0; --d) w += c_issue(((p - d) % 4 + 4) % 4, NF);
+  int w = (((p + 2) & 3) < NF) ? RPP : 0;
+  for (int d = 5; d >= 0; --d) w += c_issue(((p - d) % 4 + 4) % 4, NF, RPP);
   if (p == 2) {
     // phase 3 also reads the whole next-tile B: its last instruction was issued at phase NF-1 of
     // the previous K-tile; after it: one A load per phase NF..3, then phases 0..2 of this tile
-    int wb = (4 - NF) + c_issue(0, NF) + c_issue(1, NF) + c_issue(2, NF);
+    int wb = (4 - NF) + c_issue(0, NF, RPP) + c_issue(1, NF, RPP) + c_issue(2, NF, RPP);
     if (wb < w) w = wb;
   }
   return w;
@@ -52,10 +54,10 @@ constexpr int wait_count(int p, int NF) {
 // the memory-operation order around it.
 // vmcnt operand at the end of phase d (0..7) of the LAST pair of K-tiles, where nothing is issued any
 // more: the steady-state count minus the loads those phases would have issued
-constexpr int drain_count(int d, int NF) {
+constexpr int drain_count(int d, int NF, int RPP) {
   if (d >= 6) return 0;  // nothing left to fetch: only LDS reads remain
-  int w = (((d + 2) & 3) < NF) ? 1 : 0;                          // B issued right after the awaited A load (phase -6+d)
-  for (int e = d - 5; e < 0; ++e) w += c_issue(((e % 4) + 4) % 4, NF);  // steady phases after it
+  int w = (((d + 2) & 3) < NF) ? RPP : 0;                        // B issued right after the awaited A load (phase -6+d)
+  for (int e = d - 5; e < 0; ++e) w += c_issue(((e % 4) + 4) % 4, NF, RPP);  // steady phases after it
   if (d == 2) {
     int wb = 4 - NF;  // A loads issued after the last B instruction of the final K-tile
     if (wb < w) w = wb;
@@ -72,30 +74,41 @@ template <int N> __device__ __forceinline__ void wait_vm_lgkm() {
 
 }  // namespace
 
-template <int NF>
-__global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(NTParams p) {
+// WR = wave rows: 2 -> 256-row tile, 8 waves, one workgroup per CU (next-tile prefetch under the
+// epilogue); 1 -> 128-row tile, 4 waves, TWO independent workgroups per CU, so one workgroup's
+// epilogue (an HBM-write burst with idle matrix cores) runs under the other's K loop.
+template <int NF, int WR>
+__global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
   constexpr int BN8 = 64 * NF;
-  constexpr int A_BYTES = 256 * 128;
+  constexpr int BM8 = 128 * WR;
+  constexpr int RPP = 2 / WR;            // B LDS-DMA rounds per phase
+  constexpr int BROWS = 32 * WR;         // B rows covered by one round (8 rows per wave)
+  constexpr int A_BYTES = BM8 * 128;
   constexpr int STAGE = A_BYTES + BN8 * 128;
   // epilogue staging (wave-private 16-row bands, fp32): padded pitch where LDS allows it; the
   // 256x256 tile uses the last 32 KiB of the 160 KiB LDS unpadded
   constexpr int WN = 16 * NF;
   constexpr int SP = (NF == 4) ? WN : WN + 4;
-  constexpr int STG_BYTES = 8 * 16 * SP * 4;
-  static_assert(2 * STAGE + STG_BYTES <= 160 * 1024, "LDS budget");
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE + STG_BYTES];
+  constexpr int STG_BYTES = 4 * WR * 16 * SP * 4;
+  // with one workgroup per CU the staging region is separate (next-tile prefetch overlaps the
+  // epilogue); with two per CU each gets 80 KiB and the staging reuses stage 0 after the K loop
+  constexpr bool PREFETCH = (WR == 2);
+  constexpr int LDS_BYTES = PREFETCH ? 2 * STAGE + STG_BYTES : 2 * STAGE;
+  static_assert(LDS_BYTES * (WR == 2 ? 1 : 2) <= 160 * 1024, "LDS budget");
+  static_assert(PREFETCH || STG_BYTES <= STAGE, "staging must fit in a stage");
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
 
-  const int tiles_m = p.M >> 8, tiles_n = p.N / BN8;
+  const int tiles_m = p.M / BM8, tiles_n = p.N / BN8;
   const int ntiles = tiles_m * tiles_n;
   int vt = blockIdx.x;  // virtual tile id of this workgroup's current tile (stride gridDim.x)
   int tm, tn;
   tile_coords(xcd_remap(vt, ntiles), tiles_m, tiles_n, tm, tn);
-  int m0 = tm << 8, n0 = tn * BN8;
+  int m0 = tm * BM8, n0 = tn * BN8;
 
   // ---- LDS-DMA addressing.  One wave-instruction = 8 tile rows x 128 B; lane -> (row lane/8,
   // LDS chunk lane%8); the global chunk is XOR-swizzled with (row & 7) = lane/8.
@@ -104,16 +117,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(NTParams p) {
   const int a_row0 = (wave >> 2) * 128 + 8 * (wave & 3);
   const bf16* a_src = p.A + (long)(m0 + a_row0 + lr) * p.lda + gch * 8;  // re-pointed per tile
   const long a_qstride = 32L * p.lda;
-  // B instruction j: wave w covers tile rows 64j + 8w .. +7
+  // B round j: wave w covers tile rows BROWS*j + 8w .. +7
   const bf16* b_src = p.B + (long)(n0 + 8 * wave + lr) * p.ldb + gch * 8;
-  const long b_jstride = 64L * p.ldb;
+  const long b_jstride = (long)BROWS * p.ldb;
   const int a_lds0 = a_row0 * 128;           // + 32q*128 + stage*STAGE
   const int b_lds0 = A_BYTES + wave * 1024;  // + j*8192 + stage*STAGE
 
   auto issue = [&](int stage, int kt, int ph) {
     char* base = smem + stage * STAGE;
     glds16(a_src + ph * a_qstride + (long)kt * 64, base + a_lds0 + ph * 4096);
-    if (ph < NF) glds16(b_src + ph * b_jstride + (long)kt * 64, base + b_lds0 + ph * 8192);
+    if (ph < NF) {
+#pragma unroll
+      for (int r = 0; r < RPP; ++r)
+        glds16(b_src + (ph * RPP + r) * b_jstride + (long)kt * 64, base + b_lds0 + (ph * RPP + r) * (BROWS * 128));
+    }
   };
 
   // ---- fragment read offsets (bytes inside a stage); row & 7 == fr & 7 for every fragment
@@ -196,18 +213,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(NTParams p) {
       __builtin_amdgcn_s_setprio(0);                                                                  \
       /* (4) publish: my share of the next phase's data has landed, my LDS reads have retired */      \
       if (DRAIN) {                                                                                    \
-        if (half == 0 && ph == 0) wait_vm_lgkm<drain_count(0, NF)>();                                 \
-        else if (half == 0 && ph == 1) wait_vm_lgkm<drain_count(1, NF)>();                            \
-        else if (half == 0 && ph == 2) wait_vm_lgkm<drain_count(2, NF)>();                            \
-        else if (half == 0 && ph == 3) wait_vm_lgkm<drain_count(3, NF)>();                            \
-        else if (half == 1 && ph == 0) wait_vm_lgkm<drain_count(4, NF)>();                            \
-        else if (half == 1 && ph == 1) wait_vm_lgkm<drain_count(5, NF)>();                            \
+        if (half == 0 && ph == 0) wait_vm_lgkm<drain_count(0, NF, RPP)>();                                 \
+        else if (half == 0 && ph == 1) wait_vm_lgkm<drain_count(1, NF, RPP)>();                            \
+        else if (half == 0 && ph == 2) wait_vm_lgkm<drain_count(2, NF, RPP)>();                            \
+        else if (half == 0 && ph == 3) wait_vm_lgkm<drain_count(3, NF, RPP)>();                            \
+        else if (half == 1 && ph == 0) wait_vm_lgkm<drain_count(4, NF, RPP)>();                            \
+        else if (half == 1 && ph == 1) wait_vm_lgkm<drain_count(5, NF, RPP)>();                            \
         else wait_vm_lgkm<0>();                                                                       \
       }                                                                                               \
-      else if (ph == 0) wait_vm_lgkm<wait_count(0, NF)>();                                            \
-      else if (ph == 1) wait_vm_lgkm<wait_count(1, NF)>();                                            \
-      else if (ph == 2) wait_vm_lgkm<wait_count(2, NF)>();                                            \
-      else wait_vm_lgkm<wait_count(3, NF)>();                                                         \
+      else if (ph == 0) wait_vm_lgkm<wait_count(0, NF, RPP)>();                                            \
+      else if (ph == 1) wait_vm_lgkm<wait_count(1, NF, RPP)>();                                            \
+      else if (ph == 2) wait_vm_lgkm<wait_count(2, NF, RPP)>();                                            \
+      else wait_vm_lgkm<wait_count(3, NF, RPP)>();                                                         \
       __builtin_amdgcn_s_barrier();                                                                   \
       asm volatile("" ::: "memory");                                                                  \
     }                                                                                                 \
@@ -223,9 +240,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(NTParams p) {
   const int em0 = m0, en0 = n0;
   vt += gridDim.x;
   const bool more = vt < ntiles;
-  if (more) {
+  auto next_tile = [&]() {
     tile_coords(xcd_remap(vt, ntiles), tiles_m, tiles_n, tm, tn);
-    m0 = tm << 8;
+    m0 = tm * BM8;
     n0 = tn * BN8;
     a_src = p.A + (long)(m0 + a_row0 + lr) * p.lda + gch * 8;
     b_src = p.B + (long)(n0 + 8 * wave + lr) * p.ldb + gch * 8;
@@ -233,11 +250,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(NTParams p) {
     for (int ph = 0; ph < 4; ++ph) issue(0, 0, ph);
 #pragma unroll
     for (int ph = 0; ph < 4; ++ph) issue(1, 1, ph);
-  }
+  };
+  if (PREFETCH && more) next_tile();
 
   // ---- epilogue: restage each 16-row fragment band through the wave-private staging region so
   // that a lane owns 4*NF consecutive columns of one row, then run the shared fused epilogue.
-  float* stg = (float*)(smem + 2 * STAGE + wave * (16 * SP * 4));
+  float* stg = (float*)(smem + (PREFETCH ? 2 * STAGE : 0) + wave * (16 * SP * 4));
   const int er = lane >> 2, ec = (lane & 3) * (4 * NF);
   const int n = en0 + wc * WN + ec;
   if (p.epi & 0x100) {  // benchmarking aid (mdt_set_tuning "nt8_skip_epilogue"): main loop only
@@ -246,6 +264,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(NTParams p) {
 #pragma unroll
       for (int j = 0; j < NF; ++j) asm volatile("" ::"v"(acc[i][j]));
     if (!more) break;
+    if (!PREFETCH) next_tile();
     continue;
   }
   // software pipeline over the 8 bands: the LDS round trip and the row-dependent global loads of
@@ -278,12 +297,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8_kernel(NTParams p) {
     nt_epilogue_finish<4 * NF>(p, m, n, v, bias, pre[i & 1]);
   }
   if (!more) break;
+  if (!PREFETCH) {  // the staging region aliases stage 0: every wave must be done with it first
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    next_tile();
+  }
   }  // persistent tile loop
 }
 
-template __global__ void gemm_nt8_kernel<2>(NTParams);
-template __global__ void gemm_nt8_kernel<3>(NTParams);
-template __global__ void gemm_nt8_kernel<4>(NTParams);
+template __global__ void gemm_nt8_kernel<2, 2>(NTParams);
+template __global__ void gemm_nt8_kernel<3, 2>(NTParams);
+template __global__ void gemm_nt8_kernel<4, 2>(NTParams);
+template __global__ void gemm_nt8_kernel<2, 1>(NTParams);
+template __global__ void gemm_nt8_kernel<3, 1>(NTParams);
 
 static int num_cus() {
   static int n = 0;
@@ -296,14 +323,21 @@ static int num_cus() {
   return n;
 }
 
-int launch_gemm_nt8(const NTParams& p, int nf, hipStream_t stream) {
-  const int ntiles = (p.M >> 8) * (p.N / (64 * nf));
-  const int cus = num_cus();
-  const int tiles = ntiles < cus ? ntiles : cus;  // one persistent workgroup per CU
-  switch (nf) {
-    case 2: hipLaunchKernelGGL(gemm_nt8_kernel<2>, dim3(tiles), dim3(512), 0, stream, p); break;
-    case 3: hipLaunchKernelGGL(gemm_nt8_kernel<3>, dim3(tiles), dim3(512), 0, stream, p); break;
-    default: hipLaunchKernelGGL(gemm_nt8_kernel<4>, dim3(tiles), dim3(512), 0, stream, p); break;
+int launch_gemm_nt8(const NTParams& p, int nf, int wr, hipStream_t stream) {
+  const int bm = 128 * wr;
+  const int ntiles = (p.M / bm) * (p.N / (64 * nf));
+  const int slots = num_cus() * (wr == 1 ? 2 : 1);  // persistent workgroups: 1 (8 waves) or 2 (4 waves) per CU
+  const int grid = ntiles < slots ? ntiles : slots;
+  const dim3 blk(256 * wr);
+  if (wr == 2) {
+    switch (nf) {
+      case 2: hipLaunchKernelGGL((gemm_nt8_kernel<2, 2>), dim3(grid), blk, 0, stream, p); break;
+      case 3: hipLaunchKernelGGL((gemm_nt8_kernel<3, 2>), dim3(grid), blk, 0, stream, p); break;
+      default: hipLaunchKernelGGL((gemm_nt8_kernel<4, 2>), dim3(grid), blk, 0, stream, p); break;
+    }
+  } else {
+    if (nf == 3) hipLaunchKernelGGL((gemm_nt8_kernel<3, 1>), dim3(grid), blk, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_nt8_kernel<2, 1>), dim3(grid), blk, 0, stream, p);
   }
   return mdt_check_launch("gemm_nt8");
 }

@@ -297,7 +297,7 @@ class Engine:
 
 
 def _nt(A, lda, Bw, ldb, M, N, K, bias=0, epi=EPI_BF16, out=0, ldo=0, out2=0, ldo2=0, outf=0, ldof=0, res=0, ldres=0,
-        gate=0, gate_ld=0, rps=1, aux=0, ldaux=0):
+        gate=0, gate_ld=0, rps=1, aux=0, ldaux=0, k_splits=0):
     a = GemmNTArgs()
     a.A, a.lda, a.B, a.ldb, a.M, a.N, a.K = A, lda, Bw, ldb, M, N, K
     a.bias, a.epi = bias or None, epi
@@ -305,6 +305,7 @@ def _nt(A, lda, Bw, ldb, M, N, K, bias=0, epi=EPI_BF16, out=0, ldo=0, out2=0, ld
     a.outf, a.ldof, a.res, a.ldres = outf or None, ldof, res or None, ldres
     a.gate, a.gate_ld, a.rows_per_sample = gate or None, gate_ld, rps
     a.aux, a.ldaux = aux or None, ldaux
+    a.k_splits = k_splits
     return a
 
 
@@ -472,8 +473,9 @@ class PassPlan:
         g.add('mdt_colsum_bf16', dmod16.data_ptr(), NM, Gp + 4 * lay.ada_b, B, NM)
         g.add('mdt_gemm_tn', C.byref(self._k(_tn(dmod16.data_ptr(), NM, sc16.data_ptr(), D, Bp, NM, D, Gp + 4 * lay.ada_w, D))))
         self._slab('ada')
+        # M = batch, N = D, K = every modulation output (221 k on XL/2): split the contraction
         g.add('mdt_gemm_nt', C.byref(self._k(_nt(dmod16.data_ptr(), NM, WT('ada'), NM, B, D, NM, epi=EPI_F32,
-                                               outf=dsc.data_ptr(), ldof=D))))
+                                               outf=dsc.data_ptr(), ldof=D, k_splits=max(1, min(64, NM // 2048))))))
         g.add('mdt_silu_bwd', dsc.data_ptr(), c.data_ptr(), dc16.data_ptr(), B * D)
         g.add('mdt_gemm_tn', C.byref(self._k(_tn(dc16.data_ptr(), D, lab16.data_ptr(), YPAD, Bp, D, YPAD,
                                                Gf('model.y_embedder.embedding_table.weight'), sp.num_classes,

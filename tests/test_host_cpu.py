@@ -81,31 +81,30 @@ def test_gemm_nt8_wait_counts():
     """The compile-time vmcnt operands of gemm_nt8 (maskdit_amd/csrc/gemm_nt8.hip: wait_count) restated:
     simulate the steady-state issue sequence and check that the awaited load is exactly the oldest of
     the W+1 most recent ones (loads retire in order)."""
-    def c_issue(p, nf):
-        return 1 + (p < nf)
+    def c_issue(p, nf, rpp):
+        return 1 + (rpp if p < nf else 0)
 
-    def wait_count(p, nf):
-        w = 1 if ((p + 2) & 3) < nf else 0
+    def wait_count(p, nf, rpp):
+        w = rpp if ((p + 2) & 3) < nf else 0
         for d in range(5, -1, -1):
-            w += c_issue((p - d) % 4, nf)
+            w += c_issue((p - d) % 4, nf, rpp)
         if p == 2:
-            w = min(w, (4 - nf) + c_issue(0, nf) + c_issue(1, nf) + c_issue(2, nf))
+            w = min(w, (4 - nf) + c_issue(0, nf, rpp) + c_issue(1, nf, rpp) + c_issue(2, nf, rpp))
         return w
 
-    for nf in (2, 3, 4):
+    for nf, rpp in ((2, 1), (3, 1), (4, 1), (2, 2), (3, 2)):  # rpp = B rounds per phase (1: 8 waves, 2: 4 waves)
         seq = []  # (kind, tile, slot)
-        need_at = {}
         for g in range(0, 40):
             t, p = divmod(g, 4)
             seq.append(('A', t + 2, p))
             if p < nf:
-                seq.append(('B', t + 2, p))
+                seq += [('B', t + 2, p * rpp + r) for r in range(rpp)]
             if g < 12:
                 continue
             # end of phase g: next phase prefetches A slot (p+2)&3 of tile t (p<=1) or t+1, and at p==2 all B of t+1
             tile = t if p <= 1 else t + 1
-            awaited = [('A', tile, (p + 2) & 3)] + ([('B', t + 1, j) for j in range(nf)] if p == 2 else [])
-            w = wait_count(p, nf)
+            awaited = [('A', tile, (p + 2) & 3)] + ([('B', t + 1, j) for j in range(nf * rpp)] if p == 2 else [])
+            w = wait_count(p, nf, rpp)
             landed = set(seq[:len(seq) - w])
             assert all(a in landed for a in awaited), (nf, g, w)
             # and the wait is not needlessly strict: with W+1 outstanding some awaited load would be in flight
@@ -115,32 +114,32 @@ def test_gemm_nt8_wait_counts():
 def test_gemm_nt8_drain_counts():
     """Tail of the same pipeline (maskdit_amd/csrc/gemm_nt8.hip: drain_count): in the last pair of
     K-tiles nothing is issued any more; the operand must still cover the load the next phase needs."""
-    def c_issue(p, nf):
-        return 1 + (p < nf)
+    def c_issue(p, nf, rpp):
+        return 1 + (rpp if p < nf else 0)
 
-    def drain_count(d, nf):
+    def drain_count(d, nf, rpp):
         if d >= 6:
             return 0
-        w = 1 if ((d + 2) & 3) < nf else 0
+        w = rpp if ((d + 2) & 3) < nf else 0
         for e in range(d - 5, 0):
-            w += c_issue(e % 4, nf)
+            w += c_issue(e % 4, nf, rpp)
         if d == 2:
             w = min(w, 4 - nf)
         return w
 
-    for nf in (2, 3, 4):
+    for nf, rpp in ((2, 1), (3, 1), (4, 1), (2, 2), (3, 2)):
         seq = []
         T = 6  # K-tiles; the last pair (tiles 4, 5) is the drain body
         for g in range(0, 4 * (T - 2)):  # steady phases issue tile t+2
             t, p = divmod(g, 4)
             seq.append(('A', t + 2, p))
             if p < nf:
-                seq.append(('B', t + 2, p))
+                seq += [('B', t + 2, p * rpp + r) for r in range(rpp)]
         for d in range(6):
             t, p = divmod(4 * (T - 2) + d, 4)
             tile = t if p <= 1 else t + 1
-            awaited = [('A', tile, (p + 2) & 3)] + ([('B', t + 1, j) for j in range(nf)] if p == 2 else [])
+            awaited = [('A', tile, (p + 2) & 3)] + ([('B', t + 1, j) for j in range(nf * rpp)] if p == 2 else [])
             awaited = [a for a in awaited if a[1] < T]
-            w = drain_count(d, nf)
+            w = drain_count(d, nf, rpp)
             landed = set(seq[:len(seq) - w]) if w else set(seq)
             assert all(a in landed for a in awaited), (nf, d, w)

@@ -55,6 +55,18 @@ def test_gemm_nt_bias(M, N, K):
     close(outf, ref, 2e-5, f'gemm_nt f32 {M}x{N}x{K}')
 
 
+def test_gemm_nt_split_k():
+    """Skinny problem with a huge contraction (stacked adaLN data-gradient shape): split-K + fp32 atomics."""
+    torch.manual_seed(23)
+    M, N, K = 200, 384, 64 * 173
+    A = bf(torch.randn(M, K, device=DEV) * 0.3)
+    W = bf(torch.randn(N, K, device=DEV) * 0.1)
+    b = torch.randn(N, device=DEV)
+    outf = torch.full((M, N), 7.0, device=DEV)  # stale contents must be cleared by the call
+    ops.gemm_nt(A, W, b, ops.EPI_F32, outf=outf, k_splits=16)
+    close(outf, A.float() @ W.float().t() + b, 2e-5, 'gemm_nt split-K')
+
+
 def test_gemm_nt_asymmetric_identity():
     """A = I catches a row/col swap in the C write (asymmetric B)."""
     K = N = 128
@@ -162,12 +174,16 @@ def test_gemm_nt8_pipelined(M, N, K):
     try:
         for kw in cases:
             got = {}
-            for v in (1, 2):
+            for v in (1, 2, 3):  # 128x128 kernel; 8-wave 256-row tiles; 4-wave 128-row tiles (2 workgroups / CU)
                 lib.mdt_set_tuning(b'gemm_nt_variant', v)
                 got[v] = ops.gemm_nt(A, W, **kw)
-            for x, y in zip(got[1], got[2]):
-                if x is not None:
-                    assert torch.equal(x, y), f'nt8 differs from the 128x128 kernel (epi {kw["epi"]})'
+            for v in (2, 3):
+                for x, y in zip(got[1], got[v]):
+                    if x is not None:
+                        assert torch.equal(x, y), f'nt8 variant {v} differs from the 128x128 kernel (epi {kw["epi"]})'
+        lib.mdt_set_tuning(b'gemm_nt_variant', 3)
+        _, _, outf3 = ops.gemm_nt(A, W, b, ops.EPI_F32)
+        close(outf3, A.float() @ W.float().t() + b, 1e-5, f'gemm_nt8 4-wave {M}x{N}x{K}')
         lib.mdt_set_tuning(b'gemm_nt_variant', 2)
         _, _, outf = ops.gemm_nt(A, W, b, ops.EPI_F32)
         close(outf, A.float() @ W.float().t() + b, 1e-5, f'gemm_nt8 {M}x{N}x{K}')

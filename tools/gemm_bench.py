@@ -40,9 +40,9 @@ def main():
         W = (torch.rand(N, K, device=dev) * 2 - 1).to(torch.bfloat16)
         b = torch.randn(N, device=dev)
         outs = {}
-        times = {1: [], 2: []}
+        times = {1: [], 2: [], 3: []}
         for r in range(args.rounds):
-            for v in (1, 2):
+            for v in (1, 2, 3):
                 L.mdt_set_tuning(b'gemm_nt_variant', v)
                 out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
                 ops.gemm_nt(A, W, b, ops.EPI_BF16, out=out)  # warm
@@ -54,12 +54,12 @@ def main():
                 L.mdt_event_elapsed_ms(ev[0], ev[1], C.byref(ms))
                 times[v].append(ms.value / args.iters)
                 outs[v] = out
-        tf = {v: 2.0 * M * N * K / (sorted(times[v])[len(times[v]) // 2] * 1e-3) / 1e12 for v in (1, 2)}
-        d = (outs[2].float() - outs[1].float()).abs().max().item()
+        tf = {v: 2.0 * M * N * K / (sorted(times[v])[len(times[v]) // 2] * 1e-3) / 1e12 for v in (1, 2, 3)}
+        d = max((outs[2].float() - outs[1].float()).abs().max().item(), (outs[3].float() - outs[1].float()).abs().max().item())
         rows = min(M, 2048)
         ref = A[:rows].float() @ W.float().t() + b
         rel = ((outs[2][:rows].float() - ref).abs().max() / ref.abs().max()).item()
-        print(f'{str((M, N, K)) + " " + tag:34s} {tf[1]:9.1f} {tf[2]:9.1f} {tf[2] / tf[1]:6.2f}  {d:12.3e}   {rel:10.3e}', flush=True)
+        print(f'{str((M, N, K)) + " " + tag:34s} {tf[1]:9.1f} {tf[2]:9.1f} {tf[2] / tf[1]:6.2f}  {d:12.3e}   {rel:10.3e}   4-wave: {tf[3]:7.1f}', flush=True)
     # fused epilogues on the pipelined kernel vs the 128x128 kernel (same arithmetic => same bits expected)
     M, N, K, Lr = 4096, 1152, 1152, 128
     A = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
