@@ -275,6 +275,7 @@ extern "C" int mdt_gemm_nt(const mdt_gemm_nt_args* a, mdt_stream_t stream) {
   const int variant = mdt_get_tuning_int(MDT_TUNE_GEMM_NT_VARIANT);
   if (variant != 1 && a->k_splits <= 1 && a->M % 128 == 0 && a->K % 128 == 0) {
     if (mdt_get_tuning_int(MDT_TUNE_NT8_SKIP_EPILOGUE)) p.epi |= 0x100;
+    if (mdt_get_tuning_int(MDT_TUNE_NT8_STAGGER)) p.epi |= 0x200;
     const bool can8 = (a->M % 256 == 0);
     if (can8 && (variant == 0 || variant == 2)) {
       int nf = (a->N % 256 == 0) ? 4 : (a->N % 192 == 0) ? 3 : 2;
@@ -286,6 +287,7 @@ extern "C" int mdt_gemm_nt(const mdt_gemm_nt_args* a, mdt_stream_t stream) {
     if (variant == 3 || (variant == 0 && tiles4 >= 384)) return launch_gemm_nt8(p, nf, 1, (hipStream_t)stream);
     p.epi &= 0xff;
   }
+  p.epi &= 0xff;
   int tiles = cdiv(a->M, BM) * (a->N / BN);
   int ks = 1;
   if (a->k_splits > 1) {

@@ -97,7 +97,7 @@ template <int CW> __device__ __forceinline__ void nt_epilogue_prefetch(const NTP
   // every field is written on every path so that the struct stays in registers (no stack object)
 #pragma unroll
   for (int q = 0; q < CW; ++q) { d.ra[q] = 0.f; d.gate[q] = 0.f; }
-  const int epi = p.epi;
+  const int epi = p.epi & 0xff;
   if (m >= p.M) {
   } else if (epi == MDT_EPI_GATE_RES) {
     const float* g = p.gate + (long)(m / p.rows_per_sample) * p.gate_ld + n;
@@ -120,7 +120,7 @@ __device__ __forceinline__ void nt_epilogue_finish(const NTParams& p, int m, int
   if (m >= p.M) return;
 #pragma unroll
   for (int q = 0; q < CW; ++q) v[q] += bias[q];
-  const int epi = p.epi;
+  const int epi = p.epi & 0xff;
   if (epi == MDT_EPI_DGELU || epi == MDT_EPI_DSILU) {
 #pragma unroll
     for (int q = 0; q < CW; ++q) v[q] *= (epi == MDT_EPI_DGELU) ? gelu_tanh_grad(d.ra[q]) : silu_grad(d.ra[q]);

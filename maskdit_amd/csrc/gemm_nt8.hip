@@ -153,6 +153,14 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
 
   const int nk = p.K >> 6;  // even, >= 2
 
+  // ---- optional stagger (p.epi bit 9): every other workgroup starts half a tile period late so that
+  // the epilogues (HBM-write bursts with idle matrix cores) of one half of the chip fall under the K
+  // loops of the other half instead of all 256 CUs bursting in lock-step.
+  if ((p.epi & 0x200) && (WR == 1 ? (blockIdx.x >= (gridDim.x >> 1)) : ((blockIdx.x & 8) != 0))) {
+    // 4-wave form: the second workgroup of each CU (dispatched in the second half of the grid)
+    const int naps = ((p.K >> 6) * 1700 + 6000) >> 13;  // ~0.7 us per K-tile + half an epilogue, in 8192-cycle naps
+    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   // ---- prologue of the first tile: K-tiles 0 and 1 in steady-state issue order
 #pragma unroll
   for (int ph = 0; ph < 4; ++ph) issue(0, 0, ph);

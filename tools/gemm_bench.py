@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--rounds', type=int, default=3)
     ap.add_argument('--tn', action='store_true')
     ap.add_argument('--ablate', action='store_true')
+    ap.add_argument('--epi', action='store_true')
     args = ap.parse_args()
     L = _lib.lib()
     dev = 'cuda'
@@ -83,7 +84,7 @@ def main():
     L.mdt_set_tuning(b'gemm_nt_variant', 0)
 
 
-if __name__ == '__main__' and '--tn' not in sys.argv and '--ablate' not in sys.argv:
+if __name__ == '__main__' and not ({'--tn', '--ablate', '--epi'} & set(sys.argv)):
     main()
 
 
@@ -163,3 +164,51 @@ def ablate_main(iters=10):
 
 if __name__ == '__main__' and '--ablate' in sys.argv:
     ablate_main()
+
+
+def epi_main(iters=10):
+    """8-wave (variant 2) vs 4-wave (variant 3) nt8 with the heavy fused epilogues of the training step."""
+    L = _lib.lib()
+    dev = 'cuda'
+    ev = [C.c_void_p() for _ in range(2)]
+    for e in ev:
+        L.mdt_event_create(C.byref(e))
+    st = torch.cuda.current_stream().cuda_stream
+    Lr = 128
+    print(f'{"shape / epilogue":44s} {"8-wave TF/s":>12s} {"4-wave TF/s":>12s}')
+    for (M, N, K), name in [((32768, 4608, 1152), 'GELU'), ((32768, 4608, 1152), 'DGELU'), ((32768, 1152, 1152), 'GATE_RES'),
+                            ((32768, 1152, 4608), 'GATE_RES'), ((32768, 3456, 1152), 'BF16'), ((32768, 1152, 3456), 'BF16'),
+                            ((32768, 1152, 4608), 'BF16'), ((65536, 2048, 512), 'GELU'), ((65536, 512, 2048), 'GATE_RES')]:
+        A = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
+        W = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
+        b = torch.randn(N, device=dev) * 0.1
+        kw = dict(bias=b, epi=getattr(ops, 'EPI_' + name))
+        if name == 'GATE_RES':
+            kw.update(res=torch.randn(M, N, device=dev), gate=torch.randn(M // Lr, N, device=dev), gate_ld=N, rows_per_sample=Lr,
+                      out=torch.empty(M, N, device=dev, dtype=torch.bfloat16), outf=torch.empty(M, N, device=dev))
+        elif name == 'DGELU':
+            kw.update(bias=None, aux=torch.randn(M, N, device=dev).to(torch.bfloat16), out=torch.empty(M, N, device=dev, dtype=torch.bfloat16))
+        elif name == 'GELU':
+            kw.update(out=torch.empty(M, N, device=dev, dtype=torch.bfloat16), out2=torch.empty(M, N, device=dev, dtype=torch.bfloat16))
+        else:
+            kw.update(out=torch.empty(M, N, device=dev, dtype=torch.bfloat16))
+        res = {}
+        for v in (2, 3, 2, 3):
+            L.mdt_set_tuning(b'gemm_nt_variant', v)
+            L.mdt_set_tuning(b'nt8_stagger', 0)  # (a staggered start of every other workgroup was tried here: no gain)
+            ops.gemm_nt(A, W, **kw)
+            L.mdt_event_record(ev[0], st)
+            for _ in range(iters):
+                ops.gemm_nt(A, W, **kw)
+            L.mdt_event_record(ev[1], st)
+            ms = C.c_float()
+            L.mdt_event_elapsed_ms(ev[0], ev[1], C.byref(ms))
+            res[v] = min(res.get(v, 1e9), ms.value / iters)
+        f = 2.0 * M * N * K
+        print(f'{str((M, N, K)) + " " + name:44s} {f / res[2] / 1e9:12.1f} {f / res[3] / 1e9:12.1f}', flush=True)
+    L.mdt_set_tuning(b'gemm_nt_variant', 0)
+    L.mdt_set_tuning(b'nt8_stagger', 0)
+
+
+if __name__ == '__main__' and '--epi' in sys.argv:
+    epi_main()
