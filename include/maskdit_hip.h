@@ -104,6 +104,15 @@ int mdt_ln_modulate_fwd(const float* x, const float* shift, const float* scale, 
 int mdt_ln_modulate_bwd(const mdt_bf16* dxn, const float* x, const float* stats, const float* scale,
                         int mod_ld, int rows_per_sample, float* dx, int accumulate, float* dshift,
                         float* dscale, int dmod_ld, int M, int D, mdt_stream_t stream);
+/* ln_modulate_bwd fused with the backward of the residual gate that produced this LayerNorm's input
+ * (x = x_prev + gate[b] * y, models/maskdit.py:190-191): after dx is final for a row, also
+ * dys = bf16(gate[b] * dx), dgate[b] += sum_l dx * y, dbias += sum_rows dys -- i.e. mdt_gate_bwd without
+ * re-reading dx. */
+int mdt_ln_modulate_bwd_gate(const mdt_bf16* dxn, const float* x, const float* stats, const float* scale,
+                             int mod_ld, int rows_per_sample, float* dx, int accumulate, float* dshift,
+                             float* dscale, int dmod_ld, int M, int D, const mdt_bf16* y, const float* gate,
+                             int gate_ld, mdt_bf16* dys, float* dgate, int dgate_ld, float* dbias,
+                             mdt_stream_t stream);
 /* backward of `x + gate * y` (models/maskdit.py:190-191): dys = bf16(gate[b] * dx),
  * dgate[b] += sum_l dx * y, dbias += sum_rows dys. */
 int mdt_gate_bwd(const float* dx, const mdt_bf16* y, const float* gate, int mod_ld,

@@ -268,6 +268,7 @@ extern "C" int mdt_gemm_nt(const mdt_gemm_nt_args* a, mdt_stream_t stream) {
   p.gate = a->gate; p.gate_ld = a->gate_ld; p.rows_per_sample = a->rows_per_sample;
   p.aux = (const bf16*)a->aux; p.ldaux = a->ldaux;
   p.k_splits = 1;
+  p.group_m = mdt_get_tuning_int(MDT_TUNE_NT8_GROUP_M);
   // large aligned problems: phase-pipelined persistent kernels (gemm_nt8.hip).  variant 0 = auto:
   // 256-row tiles, one 8-wave workgroup per CU (measured best inside the training step); M % 256 != 0
   // falls to 128-row tiles with two 4-wave workgroups per CU (epilogue of one overlaps the K loop of

@@ -19,6 +19,7 @@ struct NTParams {
   const float* gate; int gate_ld; int rows_per_sample;
   const bf16* aux; int ldaux;
   int k_splits;
+  int group_m;  // tile-order group height (0 = GROUP_M)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -30,11 +31,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return base + idx;
 }
 
-__device__ __forceinline__ void tile_coords(int s, int tiles_m, int tiles_n, int& tm, int& tn) {
-  int per_group = GROUP_M * tiles_n;
+__device__ __forceinline__ void tile_coords(int s, int tiles_m, int tiles_n, int& tm, int& tn, int group_m = GROUP_M) {
+  int per_group = group_m * tiles_n;
   int group = s / per_group;
-  int first_m = group * GROUP_M;
-  int gm = min(tiles_m - first_m, GROUP_M);
+  int first_m = group * group_m;
+  int gm = min(tiles_m - first_m, group_m);
   int in = s - group * per_group;
   tm = first_m + in % gm;
   tn = in / gm;

@@ -107,7 +107,8 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
   const int ntiles = tiles_m * tiles_n;
   int vt = blockIdx.x;  // virtual tile id of this workgroup's current tile (stride gridDim.x)
   int tm, tn;
-  tile_coords(xcd_remap(vt, ntiles), tiles_m, tiles_n, tm, tn);
+  const int group_m = p.group_m > 0 ? p.group_m : GROUP_M;
+  tile_coords(xcd_remap(vt, ntiles), tiles_m, tiles_n, tm, tn, group_m);
   int m0 = tm * BM8, n0 = tn * BN8;
 
   // ---- LDS-DMA addressing.  One wave-instruction = 8 tile rows x 128 B; lane -> (row lane/8,
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
   vt += gridDim.x;
   const bool more = vt < ntiles;
   auto next_tile = [&]() {
-    tile_coords(xcd_remap(vt, ntiles), tiles_m, tiles_n, tm, tn);
+    tile_coords(xcd_remap(vt, ntiles), tiles_m, tiles_n, tm, tn, group_m);
     m0 = tm * BM8;
     n0 = tn * BN8;
     a_src = p.A + (long)(m0 + a_row0 + lr) * p.lda + gch * 8;

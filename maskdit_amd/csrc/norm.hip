@@ -68,12 +68,20 @@ __global__ __launch_bounds__(256) void ln_modulate_fwd_kernel(const float* __res
 
 // ------------------------------------------------------------------------------------------
 // grid (B, splits): workgroup handles rows [s*chunk, (s+1)*chunk) of sample b, 4 waves.
+template <bool FUSE_GATE>
 __global__ __launch_bounds__(256) void ln_modulate_bwd_kernel(const bf16* __restrict__ dxn, const float* __restrict__ x,
                                                               const float* __restrict__ stats, const float* __restrict__ scale,
                                                               int mod_ld, int rows_per_sample, int chunk,
                                                               float* __restrict__ dx, int accumulate,
                                                               float* __restrict__ dshift, float* __restrict__ dscale,
-                                                              int dmod_ld, int D) {
+                                                              int dmod_ld, int D,
+                                                              // optional fused backward of the residual gate that FED this
+                                                              // LayerNorm's input (x = x_prev + gate * y): the finished dx row is
+                                                              // still in registers, so dys = bf16(gate*dx), dgate += dx*y and
+                                                              // dbias += dys cost one extra read of y and one write of dys
+                                                              const bf16* __restrict__ gy, const float* __restrict__ ggate,
+                                                              int ggate_ld, bf16* __restrict__ gdys, float* __restrict__ gdgate,
+                                                              int gdgate_ld, float* __restrict__ gdbias) {
   __shared__ float red[2][4][MAXV * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x;
@@ -91,6 +99,16 @@ __global__ __launch_bounds__(256) void ln_modulate_bwd_kernel(const bf16* __rest
       f32x4 t = *(const f32x4*)(sc + 4 * c);
       scl[i] = (f32x4){1.f + t[0], 1.f + t[1], 1.f + t[2], 1.f + t[3]};
     }
+  }
+  constexpr bool fuse_gate = FUSE_GATE;
+  f32x4 gt[MAXV], a_g[MAXV], a_b[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    int c = lane + 64 * i;
+    a_g[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    a_b[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    gt[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (fuse_gate && c < nv) gt[i] = *(const f32x4*)(ggate + (long)b * ggate_ld + 4 * c);
   }
   const float invD = 1.f / (float)D;
   for (int r = r_begin + wave; r < r_end; r += 4) {
@@ -135,6 +153,17 @@ __global__ __launch_bounds__(256) void ln_modulate_bwd_kernel(const bf16* __rest
           o[0] += p[0]; o[1] += p[1]; o[2] += p[2]; o[3] += p[3];
         }
         *(f32x4*)(dr + 4 * c) = o;
+        if (fuse_gate) {
+          bf16x4 yv = *(const bf16x4*)(gy + row * D + 4 * c);
+          bf16x4 dy;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            a_g[i][e] += o[e] * bf2f(yv[e]);
+            dy[e] = f2bf(o[e] * gt[i][e]);
+            a_b[i][e] += bf2f(dy[e]);
+          }
+          *(bf16x4*)(gdys + row * D + 4 * c) = dy;
+        }
       }
     }
   }
@@ -156,6 +185,27 @@ __global__ __launch_bounds__(256) void ln_modulate_bwd_kernel(const bf16* __rest
     float s1 = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
     atomic_add_f32(dshift + (long)b * dmod_ld + c, s0);
     atomic_add_f32(dscale + (long)b * dmod_ld + c, s1);
+  }
+  if (fuse_gate) {  // same reduction for the gate / bias partials (the LDS buffer is reused)
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      int c = lane + 64 * i;
+      if (c < nv) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          red[0][wave][4 * c + e] = a_g[i][e];
+          red[1][wave][4 * c + e] = a_b[i][e];
+        }
+      }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+      float s0 = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+      float s1 = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+      atomic_add_f32(gdgate + (long)b * gdgate_ld + c, s0);
+      if (gdbias) atomic_add_f32(gdbias + c, s1);
+    }
   }
 }
 
@@ -285,9 +335,28 @@ extern "C" int mdt_ln_modulate_bwd(const mdt_bf16* dxn, const float* x, const fl
   int B = M / rows_per_sample;
   int chunk = pick_chunk(B, rows_per_sample);
   dim3 grid(B, cdiv(rows_per_sample, chunk));
-  hipLaunchKernelGGL(ln_modulate_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dxn, x, stats,
-                     scale, mod_ld, rows_per_sample, chunk, dx, accumulate, dshift, dscale, dmod_ld, D);
+  hipLaunchKernelGGL(ln_modulate_bwd_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dxn, x, stats,
+                     scale, mod_ld, rows_per_sample, chunk, dx, accumulate, dshift, dscale, dmod_ld, D,
+                     (const bf16*)nullptr, (const float*)nullptr, 0, (bf16*)nullptr, (float*)nullptr, 0, (float*)nullptr);
   return mdt_check_launch("ln_modulate_bwd");
+}
+
+extern "C" int mdt_ln_modulate_bwd_gate(const mdt_bf16* dxn, const float* x, const float* stats, const float* scale,
+                                        int mod_ld, int rows_per_sample, float* dx, int accumulate, float* dshift,
+                                        float* dscale, int dmod_ld, int M, int D, const mdt_bf16* y, const float* gate,
+                                        int gate_ld, mdt_bf16* dys, float* dgate, int dgate_ld, float* dbias,
+                                        mdt_stream_t stream) {
+  MDT_REQUIRE(dxn && x && stats && scale && dx && dshift && dscale, "ln_modulate_bwd_gate: null pointer");
+  MDT_REQUIRE(y && gate && dys && dgate, "ln_modulate_bwd_gate: null gate operand");
+  MDT_REQUIRE(D % 4 == 0 && D <= MAXV * 256, "ln_modulate_bwd_gate: D must be a multiple of 4 and <= 1280");
+  MDT_REQUIRE(M > 0 && rows_per_sample > 0 && M % rows_per_sample == 0, "ln_modulate_bwd_gate: M must be B*rows_per_sample");
+  int B = M / rows_per_sample;
+  int chunk = pick_chunk(B, rows_per_sample);
+  dim3 grid(B, cdiv(rows_per_sample, chunk));
+  hipLaunchKernelGGL(ln_modulate_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dxn, x, stats,
+                     scale, mod_ld, rows_per_sample, chunk, dx, accumulate, dshift, dscale, dmod_ld, D, (const bf16*)y,
+                     gate, gate_ld, (bf16*)dys, dgate, dgate_ld, dbias);
+  return mdt_check_launch("ln_modulate_bwd_gate");
 }
 
 extern "C" int mdt_gate_bwd(const float* dx, const mdt_bf16* y, const float* gate, int mod_ld, int rows_per_sample,

@@ -43,6 +43,10 @@ MODEL_CONFIGS = {  # models/maskdit.py:649-715  name -> (depth, hidden, patch, h
 }
 YPAD = 1024  # label one-hot width padded to a multiple of 128 for the GEMMs
 LIVE_ENGINES: 'weakref.WeakSet' = weakref.WeakSet()  # lets the optimizer map a parameter view back to its arena
+# mdt_ln_modulate_bwd_gate (LayerNorm backward + the following residual-gate backward in one pass) saves 4 of
+# 22 B/element but needs 214 VGPRs (2 waves/SIMD): measured 215 us vs 111 + 46 us for the two separate
+# kernels on XL/2, so the plans use the separate kernels.  Flip to re-measure after a register diet.
+FUSE_LN_GATE = False
 
 
 def _rup(x, m):
@@ -446,8 +450,11 @@ class PassPlan:
               Gf('model.final_layer.linear.weight'), Gf('model.final_layer.linear.bias'), dmod.data_ptr() + 4 * ofin,
               dmod.data_ptr() + 4 * (ofin + Dd), NM, B, T, Dd, sp.C, sp.patch)
         for i in reversed(range(sp.ddepth)):
+            # the LN1 backward that ends block i also runs the MLP-gate backward that would open block i-1
+            nxt = self._gate_info(f'model.decoder_blocks.{i - 1}', 'd', i - 1, mod, dmod, sp.mod_off('dec', i - 1), Dd, Gf) \
+                if (i > 0 and FUSE_LN_GATE) else None
             self._block_bwd(f'model.decoder_blocks.{i}', 'd', i, xs_d[i], mod, dmod, sp.mod_off('dec', i), Dd, sp.dheads, T, Md,
-                            dxd, Gf)
+                            dxd, Gf, fuse_next=nxt, skip_first_gate=(FUSE_LN_GATE and i < sp.ddepth - 1))
             self._slab(f'dec{i}')
         dxdec = self.b16('dxdec', Me, Dd)
         g.add('mdt_unmask_bwd', dxd.data_ptr(), ids32.data_ptr() if self.masked else None, 2 * T, dxdec.data_ptr(),
@@ -457,10 +464,18 @@ class PassPlan:
         g.add('mdt_colsum_bf16', dxdec.data_ptr(), Dd, Gf('model.decoder_layer.linear.bias'), Me, Dd)
         g.add('mdt_gemm_nt', C.byref(self._k(_nt(dxdec.data_ptr(), Dd, WT('model.decoder_layer.linear.weight'), Dd, Me, D, Dd,
                                                epi=EPI_BF16, out=ws['dxn'].data_ptr(), ldo=D))))
-        g.add('mdt_ln_modulate_bwd', ws['dxn'].data_ptr(), xs_e[-1].data_ptr(), st_dl.data_ptr(), mod.data_ptr() + 4 * (odl + D),
-              NM, L, dxe.data_ptr(), 0, dmod.data_ptr() + 4 * odl, dmod.data_ptr() + 4 * (odl + D), NM, Me, D)
+        if FUSE_LN_GATE:
+            top = self._gate_info(f'model.blocks.{sp.depth - 1}', 'e', sp.depth - 1, mod, dmod, sp.mod_off('enc', sp.depth - 1), D, Gf)
+            g.add('mdt_ln_modulate_bwd_gate', ws['dxn'].data_ptr(), xs_e[-1].data_ptr(), st_dl.data_ptr(), mod.data_ptr() + 4 * (odl + D),
+                  NM, L, dxe.data_ptr(), 0, dmod.data_ptr() + 4 * odl, dmod.data_ptr() + 4 * (odl + D), NM, Me, D, *top)
+        else:
+            g.add('mdt_ln_modulate_bwd', ws['dxn'].data_ptr(), xs_e[-1].data_ptr(), st_dl.data_ptr(), mod.data_ptr() + 4 * (odl + D),
+                  NM, L, dxe.data_ptr(), 0, dmod.data_ptr() + 4 * odl, dmod.data_ptr() + 4 * (odl + D), NM, Me, D)
         for i in reversed(range(sp.depth)):
-            self._block_bwd(f'model.blocks.{i}', 'e', i, xs_e[i], mod, dmod, sp.mod_off('enc', i), D, sp.heads, L, Me, dxe, Gf)
+            nxt = self._gate_info(f'model.blocks.{i - 1}', 'e', i - 1, mod, dmod, sp.mod_off('enc', i - 1), D, Gf) \
+                if (i > 0 and FUSE_LN_GATE) else None
+            self._block_bwd(f'model.blocks.{i}', 'e', i, xs_e[i], mod, dmod, sp.mod_off('enc', i), D, sp.heads, L, Me, dxe, Gf,
+                            fuse_next=nxt, skip_first_gate=FUSE_LN_GATE)
             self._slab(f'enc{i}')
         g.add('mdt_patch_embed_bwd', xin.data_ptr(), None, dxe.data_ptr(), ids32.data_ptr() if ids32 is not None else None,
               2 * T, Gf('model.x_embedder.proj.weight'), Gf('model.x_embedder.proj.bias'), B, sp.C, sp.R, sp.patch, L, D)
@@ -544,8 +559,19 @@ class PassPlan:
                                                res=xmid.data_ptr(), ldres=W, gate=g2, gate_ld=NM, rps=rows))))
         return xout
 
-    def _block_bwd(self, prefix, tag, i, x_in, mod, dmod, moff, W, heads, rows, M, dx, Gf):
-        """Backward of DiTBlock: dx (fp32 residual-stream gradient) is updated in place."""
+    def _gate_info(self, prefix, tag, i, mod, dmod, moff, W, Gf):
+        """Trailing arguments of mdt_ln_modulate_bwd_gate for the MLP residual gate of block (tag, i):
+        (y = fc2 output, gate, gate_ld, dys, dgate, dgate_ld, dbias)."""
+        NM = self.eng.sp.n_mod
+        ym = self.buf[f'ym_{tag}{i}']
+        return (ym.data_ptr(), mod.data_ptr() + 4 * (moff + 5 * W), NM, self._ws['dys'].data_ptr(),
+                dmod.data_ptr() + 4 * (moff + 5 * W), NM, Gf(f'{prefix}.mlp.fc2.bias'))
+
+    def _block_bwd(self, prefix, tag, i, x_in, mod, dmod, moff, W, heads, rows, M, dx, Gf, fuse_next=None, skip_first_gate=False):
+        """Backward of DiTBlock: dx (fp32 residual-stream gradient) is updated in place.  The gate
+        backward that opens the block is folded into the LayerNorm backward that precedes it in stream
+        order (`skip_first_gate`), and the block's last LayerNorm backward carries the next block's
+        (`fuse_next`)."""
         eng, lay, g, ws = self.eng, self.eng.lay, self.bwd, self._ws
         NM = eng.sp.n_mod
         hd = W // heads
@@ -564,23 +590,32 @@ class PassPlan:
         dxp = dx.data_ptr()
         K = self._k
         # --- MLP branch: x_out = x_mid + g2 * (fc2(gelu(fc1(xn2))))
-        g.add('mdt_gate_bwd', dxp, ym.data_ptr(), g2, NM, rows, dys, dg2, NM, Gn('mlp.fc2.bias'), M, W)
+        if not skip_first_gate:
+            g.add('mdt_gate_bwd', dxp, ym.data_ptr(), g2, NM, rows, dys, dg2, NM, Gn('mlp.fc2.bias'), M, W)
         g.add('mdt_gemm_tn', C.byref(K(_tn(dys, W, a.data_ptr(), 4 * W, M, W, 4 * W, Gn('mlp.fc2.weight'), 4 * W))))
         g.add('mdt_gemm_nt', C.byref(K(_nt(dys, W, WT('mlp.fc2.weight'), W, M, 4 * W, W, epi=EPI_DGELU, out=dh, ldo=4 * W,
                                          aux=h.data_ptr(), ldaux=4 * W))))
         g.add('mdt_gemm_tn', C.byref(K(_tn(dh, 4 * W, xn2.data_ptr(), W, M, 4 * W, W, Gn('mlp.fc1.weight'), W))))
         g.add('mdt_colsum_bf16', dh, 4 * W, Gn('mlp.fc1.bias'), M, 4 * W)
         g.add('mdt_gemm_nt', C.byref(K(_nt(dh, 4 * W, WT('mlp.fc1.weight'), 4 * W, M, W, 4 * W, epi=EPI_BF16, out=dxn, ldo=W))))
-        g.add('mdt_ln_modulate_bwd', dxn, xmid.data_ptr(), st2.data_ptr(), sc2, NM, rows, dxp, 1, dsh2, dsc2, NM, M, W)
         # --- attention branch: x_mid = x_in + g1 * proj(attn(qkv(xn1)))
-        g.add('mdt_gate_bwd', dxp, ya.data_ptr(), g1, NM, rows, dys, dg1, NM, Gn('attn.proj.bias'), M, W)
+        if FUSE_LN_GATE:  # the gate backward rides on LN2's backward
+            g.add('mdt_ln_modulate_bwd_gate', dxn, xmid.data_ptr(), st2.data_ptr(), sc2, NM, rows, dxp, 1, dsh2, dsc2, NM, M, W,
+                  ya.data_ptr(), g1, NM, dys, dg1, NM, Gn('attn.proj.bias'))
+        else:
+            g.add('mdt_ln_modulate_bwd', dxn, xmid.data_ptr(), st2.data_ptr(), sc2, NM, rows, dxp, 1, dsh2, dsc2, NM, M, W)
+            g.add('mdt_gate_bwd', dxp, ya.data_ptr(), g1, NM, rows, dys, dg1, NM, Gn('attn.proj.bias'), M, W)
         g.add('mdt_gemm_tn', C.byref(K(_tn(dys, W, ao.data_ptr(), W, M, W, W, Gn('attn.proj.weight'), W))))
         g.add('mdt_gemm_nt', C.byref(K(_nt(dys, W, WT('attn.proj.weight'), W, M, W, W, epi=EPI_BF16, out=dao, ldo=W))))
         g.add('mdt_attn_bwd', qkv.data_ptr(), ao.data_ptr(), dao, lse.data_ptr(), delta, dqkv, B, rows, heads, hd)
         g.add('mdt_gemm_tn', C.byref(K(_tn(dqkv, 3 * W, xn1.data_ptr(), W, M, 3 * W, W, Gn('attn.qkv.weight'), W))))
         g.add('mdt_colsum_bf16', dqkv, 3 * W, Gn('attn.qkv.bias'), M, 3 * W)
         g.add('mdt_gemm_nt', C.byref(K(_nt(dqkv, 3 * W, WT('attn.qkv.weight'), 3 * W, M, W, 3 * W, epi=EPI_BF16, out=dxn, ldo=W))))
-        g.add('mdt_ln_modulate_bwd', dxn, x_in.data_ptr(), st1.data_ptr(), sc1, NM, rows, dxp, 1, dsh1, dsc1, NM, M, W)
+        if fuse_next is not None:
+            g.add('mdt_ln_modulate_bwd_gate', dxn, x_in.data_ptr(), st1.data_ptr(), sc1, NM, rows, dxp, 1, dsh1, dsc1, NM, M, W,
+                  *fuse_next)
+        else:
+            g.add('mdt_ln_modulate_bwd', dxn, x_in.data_ptr(), st1.data_ptr(), sc1, NM, rows, dxp, 1, dsh1, dsc1, NM, M, W)
 
     # ---- execution ---------------------------------------------------------------------------
     def run_forward(self):

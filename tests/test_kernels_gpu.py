@@ -260,6 +260,38 @@ def test_ln_modulate_fwd_bwd(B_, L, D):
     close(dx2, x.grad, 1e-4, 'ln_mod dx (overwrite)')
 
 
+def test_ln_modulate_bwd_gate_fused():
+    """LayerNorm-modulate backward fused with the backward of the residual gate that fed it ==
+    mdt_ln_modulate_bwd followed by mdt_gate_bwd on the updated dx."""
+    torch.manual_seed(31)
+    B_, L, D = 3, 128, 1152
+    M = B_ * L
+    x = torch.randn(M, D, device=DEV) * 2 + 0.3
+    mod = torch.randn(B_, 3 * D, device=DEV) * 0.5
+    _, stats = ops.ln_modulate_fwd(x, mod[:, :D], mod[:, 2 * D:], 3 * D, L)
+    dxn = bf(torch.randn(M, D, device=DEV))
+    dx0 = torch.randn(M, D, device=DEV)
+    y = bf(torch.randn(M, D, device=DEV))
+    gate = mod[:, D:2 * D]
+    # reference sequence
+    dx_a = dx0.clone()
+    dmod_a = torch.zeros(B_, 3 * D, device=DEV)
+    ops.ln_modulate_bwd(dxn, x, stats, mod[:, 2 * D:], 3 * D, L, dx_a, True, dmod_a[:, :D], dmod_a[:, 2 * D:], 3 * D)
+    dbias_a = torch.zeros(D, device=DEV)
+    dys_a = ops.gate_bwd(dx_a, y, gate, 3 * D, L, dmod_a[:, D:2 * D], 3 * D, dbias_a)
+    # fused
+    dx_b = dx0.clone()
+    dmod_b = torch.zeros(B_, 3 * D, device=DEV)
+    dbias_b = torch.zeros(D, device=DEV)
+    dys_b = torch.empty(M, D, device=DEV, dtype=torch.bfloat16)
+    call('mdt_ln_modulate_bwd_gate', dxn.data_ptr(), x.data_ptr(), stats.data_ptr(), mod[:, 2 * D:].data_ptr(), 3 * D, L,
+         dx_b.data_ptr(), 1, dmod_b[:, :D].data_ptr(), dmod_b[:, 2 * D:].data_ptr(), 3 * D, M, D, y.data_ptr(), gate.data_ptr(),
+         3 * D, dys_b.data_ptr(), dmod_b[:, D:2 * D].data_ptr(), 3 * D, dbias_b.data_ptr(), sp())
+    assert torch.equal(dx_a, dx_b) and torch.equal(dys_a, dys_b)
+    close(dmod_b, dmod_a, 1e-5, 'fused dmod (shift | gate | scale)')
+    close(dbias_b, dbias_a, 1e-5, 'fused dbias')
+
+
 def test_gate_bwd_and_colsum():
     torch.manual_seed(5)
     B_, L, D = 3, 128, 1152

@@ -27,6 +27,7 @@ def main():
     ap.add_argument('--tn', action='store_true')
     ap.add_argument('--ablate', action='store_true')
     ap.add_argument('--epi', action='store_true')
+    ap.add_argument('--group', action='store_true')
     args = ap.parse_args()
     L = _lib.lib()
     dev = 'cuda'
@@ -84,7 +85,7 @@ def main():
     L.mdt_set_tuning(b'gemm_nt_variant', 0)
 
 
-if __name__ == '__main__' and not ({'--tn', '--ablate', '--epi'} & set(sys.argv)):
+if __name__ == '__main__' and not ({'--tn', '--ablate', '--epi', '--group'} & set(sys.argv)):
     main()
 
 
@@ -212,3 +213,38 @@ def epi_main(iters=10):
 
 if __name__ == '__main__' and '--epi' in sys.argv:
     epi_main()
+
+
+def group_main(iters=10):
+    """nt8 tile-order group height sweep (L2 reuse of the A row-panels vs the B column-panels)."""
+    L = _lib.lib()
+    dev = 'cuda'
+    ev = [C.c_void_p() for _ in range(2)]
+    for e in ev:
+        L.mdt_event_create(C.byref(e))
+    st = torch.cuda.current_stream().cuda_stream
+    gms = (2, 4, 8, 16, 32)
+    print(f'{"shape":30s} ' + ' '.join(f'gm={g:<6d}' for g in gms))
+    for M, N, K in [(32768, 1152, 1152), (32768, 3456, 1152), (32768, 4608, 1152), (32768, 1152, 4608), (65536, 2048, 512), (65536, 512, 2048)]:
+        A = (torch.rand(M, K, device=dev) * 2 - 1).to(torch.bfloat16)
+        W = (torch.rand(N, K, device=dev) * 2 - 1).to(torch.bfloat16)
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        res = {}
+        for rep in range(2):
+            for gm in gms:
+                L.mdt_set_tuning(b'nt8_group_m', gm)
+                ops.gemm_nt(A, W, None, ops.EPI_BF16, out=out)
+                L.mdt_event_record(ev[0], st)
+                for _ in range(iters):
+                    ops.gemm_nt(A, W, None, ops.EPI_BF16, out=out)
+                L.mdt_event_record(ev[1], st)
+                ms = C.c_float()
+                L.mdt_event_elapsed_ms(ev[0], ev[1], C.byref(ms))
+                res[gm] = min(res.get(gm, 1e9), ms.value / iters)
+        f = 2.0 * M * N * K
+        print(f'{str((M, N, K)):30s} ' + ' '.join(f'{f / res[g] / 1e9:9.1f}' for g in gms), flush=True)
+    L.mdt_set_tuning(b'nt8_group_m', 0)
+
+
+if __name__ == '__main__' and '--group' in sys.argv:
+    group_main()
