@@ -41,6 +41,38 @@ __device__ __forceinline__ void stage_tile(char* lds, const bf16* g, long ld, in
     *(bf16x8*)(lds + r * C::PITCH + c * 16) = v;
   }
 }
+// The same staging split in two (global -> registers, registers -> LDS) so that the loads of row
+// block i+1 are in flight while block i is being multiplied (PMC before: 70 % of wave cycles parked
+// in s_waitcnt / s_barrier behind the synchronous stage).
+template <int HD> struct TileRegs {
+  static constexpr int N = (64 * AttnCfg<HD>::CH + 255) / 256;
+  bf16x8 v[N];
+};
+template <int HD>
+__device__ __forceinline__ void tile_load(TileRegs<HD>& t, const bf16* g, long ld, int tid) {
+  using C = AttnCfg<HD>;
+#pragma unroll
+  for (int i = 0; i < TileRegs<HD>::N; ++i) {
+    int idx = tid + 256 * i;
+    if (idx < 64 * C::CH) {
+      int r = idx / C::CH, c = idx - r * C::CH;
+      t.v[i] = *(const bf16x8*)(g + (long)r * ld + c * 8);
+    }
+  }
+}
+template <int HD>
+__device__ __forceinline__ void tile_store(const TileRegs<HD>& t, char* lds, int tid) {
+  using C = AttnCfg<HD>;
+#pragma unroll
+  for (int i = 0; i < TileRegs<HD>::N; ++i) {
+    int idx = tid + 256 * i;
+    if (idx < 64 * C::CH) {
+      int r = idx / C::CH, c = idx - r * C::CH;
+      *(bf16x8*)(lds + r * C::PITCH + c * 16) = t.v[i];
+    }
+  }
+}
+
 template <int HD>
 __device__ __forceinline__ void zero_pad(char* lds, int tid) {
   using C = AttnCfg<HD>;
@@ -162,6 +194,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
   for (int f = 0; f < C::NFRAG; ++f) o[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float m_run = -1e30f, l_run = 0.f;
 
+  // (register-prefetching the next key block, as the backward kernels do, measured 2-15 % SLOWER here:
+  // the forward is bound by its dependent LDS-read -> MFMA chains, and the extra 38 VGPRs cost occupancy)
   for (int kb = 0; kb < L; kb += 64) {
     __syncthreads();
     stage_tile<HD>(Ks, base + (long)kb * ld + D, ld, tid);
@@ -266,11 +300,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
 #pragma unroll
   for (int f = 0; f < C::NFRAG; ++f) dq[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  TileRegs<HD> kreg, vreg;
+  tile_load<HD>(kreg, base + D, ld, tid);
+  tile_load<HD>(vreg, base + 2 * D, ld, tid);
   for (int kb = 0; kb < L; kb += 64) {
     __syncthreads();
-    stage_tile<HD>(Ks, base + (long)kb * ld + D, ld, tid);
-    stage_tile<HD>(Vs, base + (long)kb * ld + 2 * D, ld, tid);
+    tile_store<HD>(kreg, Ks, tid);
+    tile_store<HD>(vreg, Vs, tid);
     __syncthreads();
+    if (kb + 64 < L) {
+      tile_load<HD>(kreg, base + (long)(kb + 64) * ld + D, ld, tid);
+      tile_load<HD>(vreg, base + (long)(kb + 64) * ld + 2 * D, ld, tid);
+    }
     f32x4 ds[4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
@@ -344,13 +385,25 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
     dv[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
+  TileRegs<HD> qreg, doreg;
+  const bf16* dobase = dout + (long)b * L * D + h * HD;
+  tile_load<HD>(qreg, base, ld, tid);
+  tile_load<HD>(doreg, dobase, D, tid);
+  float stat = 0.f;  // lse (threads 0..63) / delta (64..127) of the block being staged
+  if (tid < 64) stat = lse[(long)bh * L + tid];
+  else if (tid < 128) stat = delta[(long)bh * L + tid - 64];
   for (int qb = 0; qb < L; qb += 64) {
     __syncthreads();
-    stage_tile<HD>(Qs, base + (long)qb * ld, ld, tid);
-    stage_tile<HD>(dOs, dout + ((long)b * L + qb) * D + h * HD, D, tid);
-    if (tid < 64) lse_s[tid] = lse[(long)bh * L + qb + tid];
-    else if (tid < 128) del_s[tid - 64] = delta[(long)bh * L + qb + tid - 64];
+    tile_store<HD>(qreg, Qs, tid);
+    tile_store<HD>(doreg, dOs, tid);
+    if (tid < 128) lse_s[tid] = stat;  // del_s == lse_s + 64
     __syncthreads();
+    if (qb + 64 < L) {
+      tile_load<HD>(qreg, base + (long)(qb + 64) * ld, ld, tid);
+      tile_load<HD>(doreg, dobase + (long)(qb + 64) * D, D, tid);
+      if (tid < 64) stat = lse[(long)bh * L + qb + 64 + tid];
+      else if (tid < 128) stat = delta[(long)bh * L + qb + 64 + tid - 64];
+    }
     // S fragments: rows = queries 16f + 4g + r, col = key i16
     f32x4 pm[4], ds[4];
 #pragma unroll
