@@ -164,9 +164,11 @@ __device__ __forceinline__ float group_max(float v) {
 }
 
 // ------------------------------------------------------------------------------------------
-// forward: grid (L/64, B*H)
+// forward: grid (L / (64*QF), B*H).  A wave owns QF fragments of 16 queries; every K / V fragment
+// fetched from LDS feeds QF MFMAs (at QF = 1 the kernel is LDS-bandwidth bound: 1 KiB of LDS reads
+// per MFMA), and with QF = 2 a 128-token sequence is one workgroup, so K and V are staged once.
 
-template <int HD>
+template <int HD, int QF>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                        float* __restrict__ lse, int L, int H, float scale_log2e) {
   using C = AttnCfg<HD>;
@@ -176,85 +178,108 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, g = lane >> 4;
   int b, h, blk;
-  attn_block_coords(L >> 6, gridDim.y / H, H, b, h, blk);
+  attn_block_coords(L / (64 * QF), gridDim.y / H, H, b, h, blk);
   const int bh = b * H + h;
   const int D = H * HD;
   const long ld = 3L * D;
-  const int q0 = blk * 64 + wave * 16;
+  const int q0 = blk * 64 * QF + wave * 16 * QF;  // + 16*qi
   const bf16* base = qkv + (long)b * L * ld + h * HD;
 
   zero_pad<HD>(Ks, tid);
   zero_pad<HD>(Vs, tid);
 
-  bf16x8 qf[C::KSTEPS];
-  load_frag_global<HD>(qf, base + (long)(q0 + i16) * ld, g);
-
-  f32x4 o[C::NFRAG];
+  bf16x8 qf[QF][C::KSTEPS];
 #pragma unroll
-  for (int f = 0; f < C::NFRAG; ++f) o[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float m_run = -1e30f, l_run = 0.f;
+  for (int qi = 0; qi < QF; ++qi) load_frag_global<HD>(qf[qi], base + (long)(q0 + 16 * qi + i16) * ld, g);
 
-  // (register-prefetching the next key block, as the backward kernels do, measured 2-15 % SLOWER here:
-  // the forward is bound by its dependent LDS-read -> MFMA chains, and the extra 38 VGPRs cost occupancy)
+  f32x4 o[QF][C::NFRAG];
+  float m_run[QF], l_run[QF];
+#pragma unroll
+  for (int qi = 0; qi < QF; ++qi) {
+#pragma unroll
+    for (int f = 0; f < C::NFRAG; ++f) o[qi][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    m_run[qi] = -1e30f;
+    l_run[qi] = 0.f;
+  }
+
+  // (register-prefetching the next key block, as the backward kernels do, measured 2-15 % SLOWER here)
   for (int kb = 0; kb < L; kb += 64) {
     __syncthreads();
     stage_tile<HD>(Ks, base + (long)kb * ld + D, ld, tid);
     stage_tile<HD>(Vs, base + (long)kb * ld + 2 * D, ld, tid);
     __syncthreads();
     // S^T fragments: rows = keys 16f + 4g + r, col = query i16
-    f32x4 s[4];
-    float mx = -1e30f;
+    f32x4 s[QF][4];
 #pragma unroll
     for (int f = 0; f < 4; ++f) {
-      s[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < C::KSTEPS; ++ks) s[f] = mfma16(frag_rows<HD>(Ks, 16 * f + i16, ks, g), qf[ks], s[f]);
+      for (int qi = 0; qi < QF; ++qi) s[qi][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s[f][r] *= scale_log2e;
-        mx = fmaxf(mx, s[f][r]);
+      for (int ks = 0; ks < C::KSTEPS; ++ks) {
+        const bf16x8 kfr = frag_rows<HD>(Ks, 16 * f + i16, ks, g);
+#pragma unroll
+        for (int qi = 0; qi < QF; ++qi) s[qi][f] = mfma16(kfr, qf[qi][ks], s[qi][f]);
       }
     }
-    mx = group_max(mx);
-    float m_new = fmaxf(m_run, mx);
-    float alpha = exp2f(m_run - m_new);
-    float psum = 0.f;
+    bf16x8 pf[QF][2];
 #pragma unroll
-    for (int f = 0; f < 4; ++f)
+    for (int qi = 0; qi < QF; ++qi) {
+      float mx = -1e30f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float pv = exp2f(s[f][r] - m_new);
-        s[f][r] = pv;
-        psum += pv;
-      }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
+      for (int f = 0; f < 4; ++f)
 #pragma unroll
-    for (int f = 0; f < C::NFRAG; ++f)
+        for (int r = 0; r < 4; ++r) {
+          s[qi][f][r] *= scale_log2e;
+          mx = fmaxf(mx, s[qi][f][r]);
+        }
+      mx = group_max(mx);
+      const float m_new = fmaxf(m_run[qi], mx);
+      const float alpha = exp2f(m_run[qi] - m_new);
+      float psum = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) o[f][r] *= alpha;
+      for (int f = 0; f < 4; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float pv = exp2f(s[qi][f][r] - m_new);
+          s[qi][f][r] = pv;
+          psum += pv;
+        }
+      l_run[qi] = l_run[qi] * alpha + psum;
+      m_run[qi] = m_new;
+#pragma unroll
+      for (int f = 0; f < C::NFRAG; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[qi][f][r] *= alpha;
+      pf[qi][0] = pack_pair(s[qi][0], s[qi][1]);
+      pf[qi][1] = pack_pair(s[qi][2], s[qi][3]);
+    }
     // O^T += V^T P^T : contraction over keys, two steps of 32
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 pf = pack_pair(s[2 * ks], s[2 * ks + 1]);
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int f = 0; f < C::NFRAG; ++f) o[f] = mfma16(frag_cols<HD>(Vs, 32 * ks, f, i16, g), pf, o[f]);
-    }
+      for (int f = 0; f < C::NFRAG; ++f) {
+        const bf16x8 vfr = frag_cols<HD>(Vs, 32 * ks, f, i16, g);
+#pragma unroll
+        for (int qi = 0; qi < QF; ++qi) o[qi][f] = mfma16(vfr, pf[qi][ks], o[qi][f]);
+      }
   }
-  float l_tot = group_sum(l_run);
-  float inv = 1.f / l_tot;
-  bf16* orow = out + ((long)b * L + q0 + i16) * D + h * HD;
 #pragma unroll
-  for (int f = 0; f < C::NFRAG; ++f) {
-    int d = 16 * f + 4 * g;
-    if (d < HD) {
-      bf16x4 v;
+  for (int qi = 0; qi < QF; ++qi) {
+    const float l_tot = group_sum(l_run[qi]);
+    const float inv = 1.f / l_tot;
+    bf16* orow = out + ((long)b * L + q0 + 16 * qi + i16) * D + h * HD;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = f2bf(o[f][r] * inv);
-      *(bf16x4*)(orow + d) = v;
+    for (int f = 0; f < C::NFRAG; ++f) {
+      int d = 16 * f + 4 * g;
+      if (d < HD) {
+        bf16x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = f2bf(o[qi][f][r] * inv);
+        *(bf16x4*)(orow + d) = v;
+      }
     }
+    if (g == 0) lse[(long)bh * L + q0 + 16 * qi + i16] = m_run[qi] + log2f(l_tot);
   }
-  if (g == 0) lse[(long)bh * L + q0 + i16] = m_run + log2f(l_tot);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -467,9 +492,18 @@ extern "C" int mdt_attn_fwd(const mdt_bf16* qkv, mdt_bf16* out, float* lse, int 
   MDT_REQUIRE(qkv && out && lse, "attn_fwd: null pointer");
   MDT_REQUIRE(B > 0 && H > 0 && L > 0 && L % 64 == 0, "attn_fwd: L must be a positive multiple of 64");
   float sl = (1.0f / sqrtf((float)hd)) * 1.4426950408889634f;
-  dim3 grid(L / 64, B * H);
-  ATTN_DISPATCH(hd, hipLaunchKernelGGL(attn_fwd_kernel<HDc>, grid, dim3(256), 0, (hipStream_t)stream,
-                                       (const bf16*)qkv, (bf16*)out, lse, L, H, sl));
+  // two query fragments per wave pay off for the narrow heads (hd <= 64: -8..-10 %); at hd 72/80 the
+  // extra registers cost occupancy and the kernel is bound by its 144-byte-segment global reads anyway
+  const int qf_knob = mdt_get_tuning_int(MDT_TUNE_ATTN_QF);
+  if (L % 128 == 0 && (qf_knob == 2 || (qf_knob == 0 && hd <= 64))) {
+    dim3 grid(L / 128, B * H);
+    ATTN_DISPATCH(hd, hipLaunchKernelGGL((attn_fwd_kernel<HDc, 2>), grid, dim3(256), 0, (hipStream_t)stream,
+                                         (const bf16*)qkv, (bf16*)out, lse, L, H, sl));
+  } else {
+    dim3 grid(L / 64, B * H);
+    ATTN_DISPATCH(hd, hipLaunchKernelGGL((attn_fwd_kernel<HDc, 1>), grid, dim3(256), 0, (hipStream_t)stream,
+                                         (const bf16*)qkv, (bf16*)out, lse, L, H, sl));
+  }
   return mdt_check_launch("attn_fwd");
 }
 

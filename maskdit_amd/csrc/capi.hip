@@ -27,6 +27,7 @@ int mdt_get_tuning_int(int key) { return (key >= 0 && key < MDT_TUNE_COUNT) ? g_
 extern "C" int mdt_set_tuning(const char* key, int value) {
   MDT_REQUIRE(key, "set_tuning: null key");
   if (!strcmp(key, "gemm_nt_variant")) { g_tuning[MDT_TUNE_GEMM_NT_VARIANT] = value; return MDT_OK; }
+  if (!strcmp(key, "attn_qf")) { g_tuning[MDT_TUNE_ATTN_QF] = value; return MDT_OK; }
   if (!strcmp(key, "nt8_group_m")) { g_tuning[MDT_TUNE_NT8_GROUP_M] = value; return MDT_OK; }
   if (!strcmp(key, "nt8_stagger")) { g_tuning[MDT_TUNE_NT8_STAGGER] = value; return MDT_OK; }
   if (!strcmp(key, "nt8_skip_epilogue")) { g_tuning[MDT_TUNE_NT8_SKIP_EPILOGUE] = value; return MDT_OK; }
