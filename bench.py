@@ -44,7 +44,9 @@ def parse():
     ap.add_argument('--model', default='DiT-XL/2')
     ap.add_argument('--resolution', type=int, default=32, help='latent resolution (32 = ImageNet-256, 64 = ImageNet-512)')
     ap.add_argument('--global-batch', type=int, default=1024)
-    ap.add_argument('--micro-batch', type=int, default=256, help='samples per forward/backward pass per GPU')
+    ap.add_argument('--micro-batch', type=int, default=0,
+                    help='samples per forward/backward pass per GPU (0 = the largest power-of-two split of the per-GPU '
+                         'batch whose saved activations fit in free HBM: 1024 in one pass on a 288 GB MI355X)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip the per-launch HIP events (roofline = null)')
     ap.add_argument('--cpu-batch', type=int, default=16)
@@ -201,7 +203,7 @@ def main():
     R = args.resolution
     per_gpu = args.global_batch // world
     assert per_gpu * world == args.global_batch, 'global batch must divide by the number of GPUs'
-    mb = min(args.micro_batch, per_gpu)
+    mb = min(args.micro_batch, per_gpu) if args.micro_batch > 0 else per_gpu
     accum = per_gpu // mb
     assert accum * mb == per_gpu
 
@@ -223,6 +225,14 @@ def main():
     opt.fuse_ema(ema, 0.9999)
     model = M.DataParallel(net) if world > 1 else net
     loss_fn = M.Losses['edm']()
+    if args.micro_batch <= 0:
+        # saved activations of one training pass: bf16/fp32 tensors listed in DESIGN.md section 2
+        sp = net.spec
+        per_sample = (sp.depth * 46080 * (sp.T // 2) * sp.D // 1152 + sp.ddepth * 20480 * sp.T) * 1.15  # +15 % workspaces
+        free = torch.cuda.mem_get_info(dev)[0]
+        while mb > 64 and per_sample * mb + 24e9 > free:
+            mb //= 2
+        accum = per_gpu // mb
 
     # synthetic data of the dataset's shape, resident in HBM: latents with std = sigma_data,
     # one-hot labels with class-dropout 0.1 applied (train.py:208-209)
