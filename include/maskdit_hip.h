@@ -64,6 +64,9 @@ typedef struct {
                    workgroup groups; outf is cleared on the stream and accumulated with fp32 atomics.
                    For skinny problems with a huge K (the stacked adaLN data-gradient:
                    M = batch, N = D, K = all modulation outputs).  0/1 = off. */
+  float* colsum; /* optional [N] fp32: colsum[n] += sum_m out[m, n] (the bf16-rounded values that are stored):
+                    the bias gradient of the layer whose output-gradient this GEMM produces
+                    (autograd of nn.Linear.bias), folded into the epilogue instead of a separate pass */
 } mdt_gemm_nt_args;
 int mdt_gemm_nt(const mdt_gemm_nt_args* a, mdt_stream_t stream);
 

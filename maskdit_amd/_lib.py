@@ -25,7 +25,7 @@ class GemmNTArgs(C.Structure):
     _fields_ = [('A', vp), ('lda', i32), ('B', vp), ('ldb', i32), ('M', i32), ('N', i32), ('K', i32),
                 ('bias', vp), ('epi', i32), ('out', vp), ('ldo', i32), ('out2', vp), ('ldo2', i32),
                 ('outf', vp), ('ldof', i32), ('res', vp), ('ldres', i32), ('gate', vp), ('gate_ld', i32),
-                ('rows_per_sample', i32), ('aux', vp), ('ldaux', i32), ('k_splits', i32)]
+                ('rows_per_sample', i32), ('aux', vp), ('ldaux', i32), ('k_splits', i32), ('colsum', vp)]
 
 
 class GemmTNArgs(C.Structure):

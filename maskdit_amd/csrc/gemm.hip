@@ -107,6 +107,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTParams p) {
   float* stg = (float*)(smem + wave * (16 * 68 * 4));
   const int er = lane >> 2, ec = (lane & 3) * 16;
   const int n = n0 + wc * 64 + ec;
+  float csum[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) csum[q] = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     __syncthreads();
@@ -122,8 +125,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NTParams p) {
       f32x4 t = *(const f32x4*)(stg + er * 68 + ec + q * 4);
       v[q * 4 + 0] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
     }
-    nt_epilogue_row<16>(p, m, n, v);
+    nt_epilogue_row<16>(p, m, n, v, csum);
   }
+  if (p.colsum) nt_colsum_flush<16>(p, n, csum, lane);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -248,6 +252,8 @@ extern "C" int mdt_gemm_nt(const mdt_gemm_nt_args* a, mdt_stream_t stream) {
   MDT_REQUIRE(a->K % BK == 0, "gemm_nt: K must be a multiple of 64");
   MDT_REQUIRE(a->lda % 8 == 0 && a->ldb % 8 == 0, "gemm_nt: lda/ldb must be multiples of 8");
   MDT_REQUIRE(((uintptr_t)a->A & 15) == 0 && ((uintptr_t)a->B & 15) == 0, "gemm_nt: operands must be 16-byte aligned");
+  MDT_REQUIRE(!(a->colsum && a->k_splits > 1), "gemm_nt: colsum cannot be combined with k_splits");
+  MDT_REQUIRE(!(a->colsum && !a->out), "gemm_nt: colsum sums the bf16 output, which needs `out`");
   switch (a->epi) {
     case MDT_EPI_BF16: MDT_REQUIRE(a->out, "gemm_nt: EPI_BF16 needs out"); break;
     case MDT_EPI_F32: MDT_REQUIRE(a->outf, "gemm_nt: EPI_F32 needs outf"); break;
@@ -269,6 +275,7 @@ extern "C" int mdt_gemm_nt(const mdt_gemm_nt_args* a, mdt_stream_t stream) {
   p.aux = (const bf16*)a->aux; p.ldaux = a->ldaux;
   p.k_splits = 1;
   p.group_m = mdt_get_tuning_int(MDT_TUNE_NT8_GROUP_M);
+  p.colsum = a->colsum;
   // large aligned problems: phase-pipelined persistent kernels (gemm_nt8.hip).  variant 0 = auto:
   // 256-row tiles, one 8-wave workgroup per CU (measured best inside the training step); M % 256 != 0
   // falls to 128-row tiles with two 4-wave workgroups per CU (epilogue of one overlaps the K loop of

@@ -20,6 +20,7 @@ struct NTParams {
   const bf16* aux; int ldaux;
   int k_splits;
   int group_m;  // tile-order group height (0 = GROUP_M)
+  float* colsum;  // optional: colsum[n] += sum over rows of the bf16-rounded `out` (bias gradient of the producer)
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -117,7 +118,7 @@ template <int CW> __device__ __forceinline__ void nt_epilogue_prefetch(const NTP
 
 template <int CW>
 __device__ __forceinline__ void nt_epilogue_finish(const NTParams& p, int m, int n, float* v, const float* bias,
-                                                   const NtPre<CW>& d) {
+                                                   const NtPre<CW>& d, float* csum) {
   if (m >= p.M) return;
 #pragma unroll
   for (int q = 0; q < CW; ++q) v[q] += bias[q];
@@ -140,6 +141,8 @@ __device__ __forceinline__ void nt_epilogue_finish(const NTParams& p, int m, int
   float y[CW];
 #pragma unroll
   for (int q = 0; q < CW; ++q) y[q] = bf2f(f2bf(v[q]));
+#pragma unroll
+  for (int q = 0; q < CW; ++q) csum[q] += y[q];  // column sums of the stored values (flushed only if p.colsum)
   if (p.out) store_bf16_row<CW>(p.out + (long)m * p.ldo + n, y);
   if (epi == MDT_EPI_GELU || epi == MDT_EPI_SILU) {
     float a[CW];
@@ -158,12 +161,26 @@ __device__ __forceinline__ void nt_epilogue_finish(const NTParams& p, int m, int
   }
 }
 
-template <int CW> __device__ __forceinline__ void nt_epilogue_row(const NTParams& p, int m, int n, float* v) {
+template <int CW> __device__ __forceinline__ void nt_epilogue_row(const NTParams& p, int m, int n, float* v, float* csum) {
   float bias[CW];
   NtPre<CW> d;
   nt_load_bias<CW>(p, n, bias);
   nt_epilogue_prefetch<CW>(p, m, n, d);
-  nt_epilogue_finish<CW>(p, m, n, v, bias, d);
+  nt_epilogue_finish<CW>(p, m, n, v, bias, d, csum);
+}
+
+// A lane's csum[CW] holds partial column sums for columns [n, n+CW) over the rows it processed (row =
+// lane >> 2 within each 16-row band): combine the 16 row-lanes that share lane & 3, one atomic per column.
+template <int CW> __device__ __forceinline__ void nt_colsum_flush(const NTParams& p, int n, float* csum, int lane) {
+#pragma unroll
+  for (int q = 0; q < CW; ++q) {
+    float s = csum[q];
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 8, 64);
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    if (lane < 4) atomic_add_f32(p.colsum + n + q, s);
+  }
 }
 
 int launch_gemm_nt8(const NTParams& p, int nf, int wr, hipStream_t stream);

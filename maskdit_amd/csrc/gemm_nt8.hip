@@ -278,7 +278,9 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
   }
   // software pipeline over the 8 bands: the LDS round trip and the row-dependent global loads of
   // band i+1 are issued before the arithmetic + stores of band i
-  float bias[4 * NF];
+  float bias[4 * NF], csum[4 * NF];
+#pragma unroll
+  for (int q = 0; q < 4 * NF; ++q) csum[q] = 0.f;
   nt_load_bias<4 * NF>(p, n, bias);
   NtPre<4 * NF> pre[2];
   nt_epilogue_prefetch<4 * NF>(p, em0 + wr * 128 + er, n, pre[0]);
@@ -303,8 +305,9 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
       nt_epilogue_prefetch<4 * NF>(p, em0 + wr * 128 + (i + 1) * 16 + er, n, pre[(i + 1) & 1]);
     }
     const int m = em0 + wr * 128 + i * 16 + er;
-    nt_epilogue_finish<4 * NF>(p, m, n, v, bias, pre[i & 1]);
+    nt_epilogue_finish<4 * NF>(p, m, n, v, bias, pre[i & 1], csum);
   }
+  if (p.colsum) nt_colsum_flush<4 * NF>(p, n, csum, lane);
   if (!more) break;
   if (!PREFETCH) {  // the staging region aliases stage 0: every wave must be done with it first
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -47,6 +47,8 @@ LIVE_ENGINES: 'weakref.WeakSet' = weakref.WeakSet()  # lets the optimizer map a 
 # 22 B/element but needs 214 VGPRs (2 waves/SIMD): measured 215 us vs 111 + 46 us for the two separate
 # kernels on XL/2, so the plans use the separate kernels.  Flip to re-measure after a register diet.
 FUSE_LN_GATE = False
+import os as _os
+FUSE_COLSUM = _os.environ.get('MDT_FUSE_COLSUM', '1') != '0'  # fc1 bias gradient out of the DGELU epilogue (A/B switch)
 
 
 def _rup(x, m):
@@ -301,7 +303,7 @@ class Engine:
 
 
 def _nt(A, lda, Bw, ldb, M, N, K, bias=0, epi=EPI_BF16, out=0, ldo=0, out2=0, ldo2=0, outf=0, ldof=0, res=0, ldres=0,
-        gate=0, gate_ld=0, rps=1, aux=0, ldaux=0, k_splits=0):
+        gate=0, gate_ld=0, rps=1, aux=0, ldaux=0, k_splits=0, colsum=0):
     a = GemmNTArgs()
     a.A, a.lda, a.B, a.ldb, a.M, a.N, a.K = A, lda, Bw, ldb, M, N, K
     a.bias, a.epi = bias or None, epi
@@ -310,6 +312,7 @@ def _nt(A, lda, Bw, ldb, M, N, K, bias=0, epi=EPI_BF16, out=0, ldo=0, out2=0, ld
     a.gate, a.gate_ld, a.rows_per_sample = gate or None, gate_ld, rps
     a.aux, a.ldaux = aux or None, ldaux
     a.k_splits = k_splits
+    a.colsum = colsum or None
     return a
 
 
@@ -593,10 +596,12 @@ class PassPlan:
         if not skip_first_gate:
             g.add('mdt_gate_bwd', dxp, ym.data_ptr(), g2, NM, rows, dys, dg2, NM, Gn('mlp.fc2.bias'), M, W)
         g.add('mdt_gemm_tn', C.byref(K(_tn(dys, W, a.data_ptr(), 4 * W, M, W, 4 * W, Gn('mlp.fc2.weight'), 4 * W))))
+        # dh = (dys W2) * gelu'(h); its column sums (= d fc1.bias) come out of the same epilogue
         g.add('mdt_gemm_nt', C.byref(K(_nt(dys, W, WT('mlp.fc2.weight'), W, M, 4 * W, W, epi=EPI_DGELU, out=dh, ldo=4 * W,
-                                         aux=h.data_ptr(), ldaux=4 * W))))
+                                         aux=h.data_ptr(), ldaux=4 * W, colsum=Gn('mlp.fc1.bias') if FUSE_COLSUM else 0))))
         g.add('mdt_gemm_tn', C.byref(K(_tn(dh, 4 * W, xn2.data_ptr(), W, M, 4 * W, W, Gn('mlp.fc1.weight'), W))))
-        g.add('mdt_colsum_bf16', dh, 4 * W, Gn('mlp.fc1.bias'), M, 4 * W)
+        if not FUSE_COLSUM:
+            g.add('mdt_colsum_bf16', dh, 4 * W, Gn('mlp.fc1.bias'), M, 4 * W)
         g.add('mdt_gemm_nt', C.byref(K(_nt(dh, 4 * W, WT('mlp.fc1.weight'), 4 * W, M, W, 4 * W, epi=EPI_BF16, out=dxn, ldo=W))))
         # --- attention branch: x_mid = x_in + g1 * proj(attn(qkv(xn1)))
         if FUSE_LN_GATE:  # the gate backward rides on LN2's backward

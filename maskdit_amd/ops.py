@@ -26,7 +26,7 @@ def _need(t, dtype, name):
 
 
 def gemm_nt(A, Bw, bias=None, epi=EPI_BF16, out=None, out2=None, outf=None, res=None, gate=None, gate_ld=0,
-            rows_per_sample=1, aux=None, M=None, k_splits=0):
+            rows_per_sample=1, aux=None, M=None, k_splits=0, colsum=None):
     """C = A[M,K] @ Bw[N,K]^T with a fused epilogue (see include/maskdit_hip.h)."""
     _need(A, torch.bfloat16, 'A')
     _need(Bw, torch.bfloat16, 'B')
@@ -48,6 +48,7 @@ def gemm_nt(A, Bw, bias=None, epi=EPI_BF16, out=None, out2=None, outf=None, res=
     a.gate, a.gate_ld, a.rows_per_sample = p(gate), gate_ld, rows_per_sample
     a.aux, a.ldaux = p(aux), (aux.stride(0) if aux is not None else 0)
     a.k_splits = k_splits
+    a.colsum = p(colsum)
     call('mdt_gemm_nt', C.byref(a), stream_ptr())
     return out, out2, outf
 

@@ -55,6 +55,23 @@ def test_gemm_nt_bias(M, N, K):
     close(outf, ref, 2e-5, f'gemm_nt f32 {M}x{N}x{K}')
 
 
+@pytest.mark.parametrize('variant', [1, 2, 3])
+def test_gemm_nt_colsum_epilogue(variant):
+    """Bias gradient folded into the epilogue: colsum[n] += sum_m bf16(out[m, n])."""
+    torch.manual_seed(24)
+    M, N, K = 1024, 1152, 256
+    A = bf(torch.randn(M, K, device=DEV) * 0.5)
+    W = bf(torch.randn(N, K, device=DEV) * 0.1)
+    aux = bf(torch.randn(M, N, device=DEV))
+    cs = torch.full((N,), 3.0, device=DEV)
+    _lib.lib().mdt_set_tuning(b'gemm_nt_variant', variant)
+    try:
+        out, _, _ = ops.gemm_nt(A, W, None, ops.EPI_DGELU, aux=aux, colsum=cs)
+    finally:
+        _lib.lib().mdt_set_tuning(b'gemm_nt_variant', 0)
+    close(cs, out.float().sum(0) + 3.0, 1e-5, f'colsum epilogue (variant {variant})')
+
+
 def test_gemm_nt_split_k():
     """Skinny problem with a huge contraction (stacked adaLN data-gradient shape): split-K + fp32 atomics."""
     torch.manual_seed(23)
