@@ -493,7 +493,8 @@ class PassPlan:
         self._slab('ada')
         # M = batch, N = D, K = every modulation output (221 k on XL/2): split the contraction
         g.add('mdt_gemm_nt', C.byref(self._k(_nt(dmod16.data_ptr(), NM, WT('ada'), NM, B, D, NM, epi=EPI_F32,
-                                               outf=dsc.data_ptr(), ldof=D, k_splits=max(1, min(64, NM // 2048))))))
+                                               outf=dsc.data_ptr(), ldof=D,
+                                               k_splits=max(1, min(64, NM // 2048, 1024 // (((B + 127) // 128) * (D // 128))))))))
         g.add('mdt_silu_bwd', dsc.data_ptr(), c.data_ptr(), dc16.data_ptr(), B * D)
         g.add('mdt_gemm_tn', C.byref(self._k(_tn(dc16.data_ptr(), D, lab16.data_ptr(), YPAD, Bp, D, YPAD,
                                                Gf('model.y_embedder.embedding_table.weight'), sp.num_classes,
