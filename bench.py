@@ -189,12 +189,19 @@ def main():
             raise SystemExit('bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)')
         args.gpus = world
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # test hook: MDT_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 over gloo, so that the N > 1 code path
+    # can be exercised on a single-GPU box (RCCL needs one device per rank); never set by the driver
+    one_dev = os.environ.get('MDT_BENCH_ONE_DEVICE') == '1'
+    dev_index = 0 if one_dev else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        if one_dev:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     import maskdit_amd as M
     from maskdit_amd import _lib
@@ -344,7 +351,7 @@ def main():
     if rank == 0:
         value = args.global_batch * args.steps / dt
         line = {
-            'metric': 'training img/sec MaskDiT-XL/2 256 mask=0.5 bs=1024' if (args.model, R) == ('DiT-XL/2', 32)
+            'metric': 'training img/sec MaskDiT-XL/2 256 mask=0.5 bs=1024' if (args.model, R, args.global_batch) == ('DiT-XL/2', 32, 1024)
             else f'training img/sec {args.model} latent{R} mask=0.5 bs={args.global_batch}',
             'value': round(value, 2), 'unit': 'img/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'strong',

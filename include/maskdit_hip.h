@@ -35,9 +35,9 @@ int mdt_set_tuning(const char* key, int value);
 enum mdt_epilogue {
   MDT_EPI_BF16 = 0,     /* out = bf16(acc + bias)                                              */
   MDT_EPI_F32 = 1,      /* outf = acc + bias   (and out = bf16 of it when out != NULL)         */
-  MDT_EPI_GELU = 2,     /* out = h = bf16(acc+bias); out2 = bf16(gelu_tanh(h))                 */
-  MDT_EPI_SILU = 3,     /* out = h; out2 = bf16(silu(h))                                       */
-  MDT_EPI_GATE_RES = 4, /* out = y = bf16(acc+bias); outf = res + gate[row/rows_per_sample]*y  */
+  MDT_EPI_GELU = 2,     /* out = h = bf16(acc+bias); out2 = bf16(gelu_tanh(h))   (out may be NULL: */
+  MDT_EPI_SILU = 3,     /* out = h; out2 = bf16(silu(h))                          inference)       */
+  MDT_EPI_GATE_RES = 4, /* out = y = bf16(acc+bias); outf = res + gate[row/rows_per_sample]*y  (out may be NULL) */
   MDT_EPI_DGELU = 5,    /* out = bf16(acc * gelu_tanh'(aux))                                   */
   MDT_EPI_DSILU = 6     /* out = bf16(acc * silu'(aux))                                        */
 };

@@ -258,9 +258,9 @@ extern "C" int mdt_gemm_nt(const mdt_gemm_nt_args* a, mdt_stream_t stream) {
     case MDT_EPI_BF16: MDT_REQUIRE(a->out, "gemm_nt: EPI_BF16 needs out"); break;
     case MDT_EPI_F32: MDT_REQUIRE(a->outf, "gemm_nt: EPI_F32 needs outf"); break;
     case MDT_EPI_GELU:
-    case MDT_EPI_SILU: MDT_REQUIRE(a->out && a->out2, "gemm_nt: activation epilogue needs out and out2"); break;
+    case MDT_EPI_SILU: MDT_REQUIRE(a->out2, "gemm_nt: activation epilogue needs out2 (out = pre-activation is optional)"); break;
     case MDT_EPI_GATE_RES:
-      MDT_REQUIRE(a->out && a->outf && a->res && a->gate && a->rows_per_sample > 0, "gemm_nt: EPI_GATE_RES needs out/outf/res/gate");
+      MDT_REQUIRE(a->outf && a->res && a->gate && a->rows_per_sample > 0, "gemm_nt: EPI_GATE_RES needs outf/res/gate (out is optional)");
       break;
     case MDT_EPI_DGELU:
     case MDT_EPI_DSILU: MDT_REQUIRE(a->out && a->aux, "gemm_nt: d-activation epilogue needs out and aux"); break;

@@ -552,14 +552,17 @@ class PassPlan:
         f.add('mdt_gemm_nt', C.byref(self._k(_nt(xn1.data_ptr(), W, Wp('attn.qkv.weight'), W, M, 3 * W, W, bias=Pf('attn.qkv.bias'),
                                                epi=EPI_BF16, out=qkv.data_ptr(), ldo=3 * W))))
         f.add('mdt_attn_fwd', qkv.data_ptr(), ao.data_ptr(), lse.data_ptr(), B, rows, heads, hd)
+        # the bf16 copies of the branch outputs (ya, ym) and the pre-activation h are saved for the
+        # backward only: inference plans skip those stores (2 of 10 resp. 2 of 4 epilogue bytes / element)
+        tr = self.train
         f.add('mdt_gemm_nt', C.byref(self._k(_nt(ao.data_ptr(), W, Wp('attn.proj.weight'), W, M, W, W, bias=Pf('attn.proj.bias'),
-                                               epi=EPI_GATE_RES, out=ya.data_ptr(), ldo=W, outf=xmid.data_ptr(), ldof=W,
+                                               epi=EPI_GATE_RES, out=ya.data_ptr() if tr else 0, ldo=W, outf=xmid.data_ptr(), ldof=W,
                                                res=x_in.data_ptr(), ldres=W, gate=g1, gate_ld=NM, rps=rows))))
         f.add('mdt_ln_modulate_fwd', xmid.data_ptr(), sh2, sc2, NM, rows, xn2.data_ptr(), st2.data_ptr(), M, W)
         f.add('mdt_gemm_nt', C.byref(self._k(_nt(xn2.data_ptr(), W, Wp('mlp.fc1.weight'), W, M, 4 * W, W, bias=Pf('mlp.fc1.bias'),
-                                               epi=EPI_GELU, out=h.data_ptr(), ldo=4 * W, out2=a.data_ptr(), ldo2=4 * W))))
+                                               epi=EPI_GELU, out=h.data_ptr() if tr else 0, ldo=4 * W, out2=a.data_ptr(), ldo2=4 * W))))
         f.add('mdt_gemm_nt', C.byref(self._k(_nt(a.data_ptr(), 4 * W, Wp('mlp.fc2.weight'), 4 * W, M, W, 4 * W, bias=Pf('mlp.fc2.bias'),
-                                               epi=EPI_GATE_RES, out=ym.data_ptr(), ldo=W, outf=xout.data_ptr(), ldof=W,
+                                               epi=EPI_GATE_RES, out=ym.data_ptr() if tr else 0, ldo=W, outf=xout.data_ptr(), ldof=W,
                                                res=xmid.data_ptr(), ldres=W, gate=g2, gate_ld=NM, rps=rows))))
         return xout
 
