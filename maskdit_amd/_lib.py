@@ -127,6 +127,11 @@ def lib():
     L.mdt_last_error.argtypes = []
     L.mdt_version.restype = i32
     L.mdt_version.argtypes = []
+    # MDT_TUNE="key=value,key=value": process-wide tuning knobs for A/B runs (mdt_set_tuning)
+    for item in filter(None, os.environ.get('MDT_TUNE', '').split(',')):
+        k, _, v = item.partition('=')
+        if L.mdt_set_tuning(k.strip().encode(), int(v)) != 0:
+            raise MaskDiTLibError(f'MDT_TUNE: unknown knob {k!r}')
     _lib = L
     return L
 

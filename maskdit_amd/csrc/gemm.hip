@@ -285,14 +285,29 @@ extern "C" int mdt_gemm_nt(const mdt_gemm_nt_args* a, mdt_stream_t stream) {
     if (mdt_get_tuning_int(MDT_TUNE_NT8_SKIP_EPILOGUE)) p.epi |= 0x100;
     if (mdt_get_tuning_int(MDT_TUNE_NT8_STAGGER)) p.epi |= 0x200;
     const bool can8 = (a->M % 256 == 0);
-    if (can8 && (variant == 0 || variant == 2)) {
-      int nf = (a->N % 256 == 0) ? 4 : (a->N % 192 == 0) ? 3 : 2;
-      long tiles8 = (long)(a->M / 256) * (a->N / (64 * nf));
-      if (variant == 2 || tiles8 >= 192) return launch_gemm_nt8(p, nf, 2, (hipStream_t)stream);
+    const int cus = 256;
+    const int nf8 = (a->N % 256 == 0) ? 4 : (a->N % 192 == 0) ? 3 : 2;
+    const int nf4 = (a->N % 192 == 0) ? 3 : 2;
+    const long tiles8 = can8 ? (long)(a->M / 256) * (a->N / (64 * nf8)) : 0;
+    const long tiles4 = (long)(a->M / 128) * (a->N / (64 * nf4));
+    if (variant == 2 && can8) return launch_gemm_nt8(p, nf8, 2, (hipStream_t)stream);
+    if (variant == 3) return launch_gemm_nt8(p, nf4, 1, (hipStream_t)stream);
+    if (variant == 0) {
+      // Cost model (tools/gemm_bench.py --small-m / default): time ~ output area walked by the busiest CU.
+      // 8-wave: whole rounds of 256 x 64*nf8 tiles.  4-wave: half-height tiles, two per CU at a time; a
+      // workgroup that is alone on its CU (odd tail) runs ~1.6x faster.  With equal areas the 8-wave form
+      // wins inside the training step (607 vs 686 ms at M = 131072: next-tile prefetch under the fused
+      // epilogues, more operand reuse), so the 4-wave form is taken only when whole-tile rounds quantise
+      // badly -- per-GPU batch 128 of the 8-GPU configuration: 685 vs 766 ms per 1024 samples.
+      double w8 = 1e30, w4 = 1e30;
+      if (can8 && tiles8 >= 192) w8 = (double)((tiles8 + cus - 1) / cus) * (64.0 * nf8);
+      if (tiles4 >= 384) {
+        const long q = (tiles4 + cus - 1) / cus;
+        w4 = ((double)(q / 2) + 0.62 * (double)(q & 1)) * (64.0 * nf4) * (a->K < 2048 ? 1.0 : 1.10);
+      }
+      if (w4 < 0.97 * w8 && w4 < 1e29) return launch_gemm_nt8(p, nf4, 1, (hipStream_t)stream);
+      if (w8 < 1e29) return launch_gemm_nt8(p, nf8, 2, (hipStream_t)stream);
     }
-    int nf = (a->N % 192 == 0) ? 3 : 2;
-    long tiles4 = (long)(a->M / 128) * (a->N / (64 * nf));
-    if (variant == 3 || (variant == 0 && tiles4 >= 384)) return launch_gemm_nt8(p, nf, 1, (hipStream_t)stream);
     p.epi &= 0xff;
   }
   p.epi &= 0xff;

@@ -28,6 +28,7 @@ def main():
     ap.add_argument('--ablate', action='store_true')
     ap.add_argument('--epi', action='store_true')
     ap.add_argument('--group', action='store_true')
+    ap.add_argument('--small-m', action='store_true')
     args = ap.parse_args()
     L = _lib.lib()
     dev = 'cuda'
@@ -85,7 +86,7 @@ def main():
     L.mdt_set_tuning(b'gemm_nt_variant', 0)
 
 
-if __name__ == '__main__' and not ({'--tn', '--ablate', '--epi', '--group'} & set(sys.argv)):
+if __name__ == '__main__' and not ({'--tn', '--ablate', '--epi', '--group', '--small-m'} & set(sys.argv)):
     main()
 
 
@@ -248,3 +249,38 @@ def group_main(iters=10):
 
 if __name__ == '__main__' and '--group' in sys.argv:
     group_main()
+
+
+def small_m_main(iters=10):
+    """Per-GPU batch 128 (the 8-GPU data-parallel configuration): M = 16384 / 32768 -- tile-count quantisation."""
+    L = _lib.lib()
+    dev = 'cuda'
+    ev = [C.c_void_p() for _ in range(2)]
+    for e in ev:
+        L.mdt_event_create(C.byref(e))
+    st = torch.cuda.current_stream().cuda_stream
+    print(f'{"shape":30s} {"v1":>8s} {"8-wave":>8s} {"4-wave":>8s}   (TF/s)')
+    for M, N, K in [(16384, 1152, 1152), (16384, 3456, 1152), (16384, 4608, 1152), (16384, 1152, 4608), (16384, 1152, 3456),
+                    (32768, 512, 512), (32768, 1536, 512), (32768, 2048, 512), (32768, 512, 2048), (8192, 1152, 1152), (8192, 4608, 1152)]:
+        A = (torch.rand(M, K, device=dev) * 2 - 1).to(torch.bfloat16)
+        W = (torch.rand(N, K, device=dev) * 2 - 1).to(torch.bfloat16)
+        out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        res = {}
+        for rep in range(2):
+            for v in (1, 2, 3):
+                L.mdt_set_tuning(b'gemm_nt_variant', v)
+                ops.gemm_nt(A, W, None, ops.EPI_BF16, out=out)
+                L.mdt_event_record(ev[0], st)
+                for _ in range(iters):
+                    ops.gemm_nt(A, W, None, ops.EPI_BF16, out=out)
+                L.mdt_event_record(ev[1], st)
+                ms = C.c_float()
+                L.mdt_event_elapsed_ms(ev[0], ev[1], C.byref(ms))
+                res[v] = min(res.get(v, 1e9), ms.value / iters)
+        f = 2.0 * M * N * K
+        print(f'{str((M, N, K)):30s} ' + ' '.join(f'{f / res[v] / 1e9:8.1f}' for v in (1, 2, 3)), flush=True)
+    L.mdt_set_tuning(b'gemm_nt_variant', 0)
+
+
+if __name__ == '__main__' and '--small-m' in sys.argv:
+    small_m_main()
