@@ -273,3 +273,52 @@ def test_sample_moments_and_class_dropout_vs_reference_fixture(golden_dir):
     torch.manual_seed(3)
     M.class_dropout_(y, 0.3)
     assert torch.equal(y, torch.eye(1000, device=DEV)[:64] * (u >= 0.3).float())
+
+
+def test_full_size_batch_properties_xl2_bs1024():
+    """BASELINE configs[1] at full size (XL/2, 256^2 latents, batch 1024, mask 0.5), forward + loss:
+    size-independent properties instead of a full-size oracle run --
+      * masking: every row is a permutation / its inverse, exactly L kept, bit-exact vs the oracle on sampled rows;
+      * batch invariance: a sample's loss inside the 1024-batch equals its loss when its 16-sample slice
+        is run alone with the same draws (different GEMM tile kernels / tile counts, same arithmetic);
+      * 4 samples of the full batch against the fp32 CPU oracle (bf16-compute tolerance)."""
+    cfg, P, net = _build('DiT-XL/2', 32, seed=9)
+    B, T = 1024, 256
+    g = torch.Generator().manual_seed(17)
+    images = 0.5 * torch.randn(B, 4, 32, 32, generator=g)
+    cls = torch.randint(0, 1000, (B,), generator=g)
+    labels = torch.zeros(B, 1000)
+    labels[torch.arange(B), cls] = 1
+    labels *= (torch.rand(B, 1, generator=g) >= 0.1).float()
+    rnd, noise = torch.randn(B, 1, 1, 1, generator=g), torch.randn(B, 4, 32, 32, generator=g)
+    mnoise = torch.rand(B, T, generator=g)
+    loss_fn = M.Losses['edm']()
+
+    def run(sl):
+        n = sl.stop - sl.start
+        md = M.get_mask(n, T, 0.5, DEV, noise=mnoise[sl].to(DEV))
+        with torch.no_grad():
+            l = loss_fn.with_draws(net, images[sl].to(DEV), labels[sl].to(DEV), rnd[sl].to(DEV), noise[sl].to(DEV), md, 0.1)
+        return l.cpu(), md
+
+    full, md = run(slice(0, B))
+    assert bool(torch.isfinite(full).all())
+    ar = torch.arange(T, device=DEV).expand(B, T)
+    ids_shuffle = md['ids32'][:, :T].long()
+    assert torch.equal(torch.sort(ids_shuffle, dim=1).values, ar)
+    assert torch.equal(torch.gather(ids_shuffle, 1, md['ids_restore']), ar)
+    assert bool((md['mask'].sum(1) == T // 2).all()) and bool((torch.gather(md['mask'], 1, md['ids_keep']) == 0).all())
+    rows = [0, 511, 1023]
+    ref_md = O.get_mask_from_noise(mnoise[rows].numpy(), 0.5)
+    assert np.array_equal(md['ids_restore'][rows].cpu().numpy(), ref_md['ids_restore'])
+    for lo in (0, 496, 1008):
+        part, _ = run(slice(lo, lo + 16))
+        rel = ((part - full[lo:lo + 16]).abs() / full[lo:lo + 16].abs()).max().item()
+        assert rel <= 2e-3, f'batch invariance broken at rows {lo}..{lo + 15}: {rel:.3e}'
+    sl = slice(1020, 1024)
+    mdict = {k: torch.from_numpy(v) for k, v in O.get_mask_from_noise(mnoise[sl].numpy(), 0.5).items()}
+    with torch.no_grad():
+        ref, _ = O.edm_loss(P, cfg, images[sl], labels[sl], rnd[sl], noise[sl], mdict, mae_loss_coef=0.1)
+    rel = ((full[sl] - ref).abs() / ref.abs()).max().item()
+    print(f'XL/2 bs1024: loss vs oracle on 4 samples rel err {rel:.3e}')
+    assert rel <= 3e-2
