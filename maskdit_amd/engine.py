@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 import weakref
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Tuple
@@ -47,8 +48,7 @@ LIVE_ENGINES: 'weakref.WeakSet' = weakref.WeakSet()  # lets the optimizer map a 
 # 22 B/element but needs 214 VGPRs (2 waves/SIMD): measured 215 us vs 111 + 46 us for the two separate
 # kernels on XL/2, so the plans use the separate kernels.  Flip to re-measure after a register diet.
 FUSE_LN_GATE = False
-import os as _os
-FUSE_COLSUM = _os.environ.get('MDT_FUSE_COLSUM', '1') != '0'  # fc1 bias gradient out of the DGELU epilogue (A/B switch)
+FUSE_COLSUM = os.environ.get('MDT_FUSE_COLSUM', '1') != '0'  # fc1 bias gradient out of the DGELU epilogue (A/B switch)
 
 
 def _rup(x, m):
