@@ -88,12 +88,15 @@ int mdt_gemm_tn(const mdt_gemm_tn_args* a, mdt_stream_t stream);
 
 /* softmax(q k^T / sqrt(hd)) v for packed qkv [B*L, 3*H*hd] (timm Attention, call site
  * models/maskdit.py:178).  out [B*L, H*hd] bf16, lse [B*H*L] f32 (log2 domain).
- * hd in {32, 64, 72, 80}; L % 64 == 0. */
-int mdt_attn_fwd(const mdt_bf16* qkv, mdt_bf16* out, float* lse, int B, int L, int H, int hd,
+ * hd in {32, 64, 72, 80}; L % 64 == 0.  L_valid (0 = L): rows >= L_valid of every sample are padding
+ * (a kept-token count rounded up to the 64-row tile): as KEYS they get zero probability, as queries their
+ * outputs are don't-care. */
+int mdt_attn_fwd(const mdt_bf16* qkv, mdt_bf16* out, float* lse, int B, int L, int H, int hd, int L_valid,
                  mdt_stream_t stream);
-/* backward of the above: dqkv [B*L, 3*H*hd] from dout; delta is [B*H*L] f32 scratch. */
+/* backward of the above: dqkv [B*L, 3*H*hd] from dout; delta is [B*H*L] f32 scratch.  With dout = 0 on the
+ * padding rows, dqkv is exactly 0 there. */
 int mdt_attn_bwd(const mdt_bf16* qkv, const mdt_bf16* out, const mdt_bf16* dout, const float* lse,
-                 float* delta, mdt_bf16* dqkv, int B, int L, int H, int hd, mdt_stream_t stream);
+                 float* delta, mdt_bf16* dqkv, int B, int L, int H, int hd, int L_valid, mdt_stream_t stream);
 
 /* ---------------------------------------------------------------- norm / modulate ------ */
 
@@ -152,11 +155,13 @@ int mdt_add_f32(const float* a, const float* b, float* out, long n, mdt_stream_t
 int mdt_silu_bwd(const float* dy, const float* x, mdt_bf16* dx, long n, mdt_stream_t stream);
 
 /* unmask_tokens + decoder_pos_embed (models/maskdit.py:157-163,543-545).
- * xdec bf16 [B,L,Dd]; restore int32 [B,T] (NULL = identity, L == T); out f32 [B,T,Dd]. */
+ * xdec bf16 [B,L_pitch,Dd] (L_pitch = 0 means L; L_pitch > L = encoder rows padded to the 64-row tile, the
+ * padding rows are ignored forward and receive zero gradient); restore int32 [B,T] (NULL = identity, L == T);
+ * out f32 [B,T,Dd]. */
 int mdt_unmask_fwd(const mdt_bf16* xdec, const int32_t* restore, int ids_ld, const float* mask_token,
-                   const float* pos, float* out, int B, int T, int L, int Dd, mdt_stream_t stream);
+                   const float* pos, float* out, int B, int T, int L, int Dd, int L_pitch, mdt_stream_t stream);
 int mdt_unmask_bwd(const float* dout, const int32_t* shuffle, int ids_ld, mdt_bf16* dxdec,
-                   float* dmask_token, int B, int T, int L, int Dd, mdt_stream_t stream);
+                   float* dmask_token, int B, int T, int L, int Dd, int L_pitch, mdt_stream_t stream);
 
 /* FinalLayer + unpatchify (models/maskdit.py:216-234,411-424): x f32 [B*T, Dd] ->
  * LN-modulate -> Linear(Dd -> p*p*C) -> F [B,C,R,R] f32. */

@@ -37,8 +37,8 @@ class GemmTNArgs(C.Structure):
 _PROTOS = {
     'mdt_gemm_nt': [C.POINTER(GemmNTArgs)],
     'mdt_gemm_tn': [C.POINTER(GemmTNArgs)],
-    'mdt_attn_fwd': [vp, vp, vp, i32, i32, i32, i32],
-    'mdt_attn_bwd': [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32],
+    'mdt_attn_fwd': [vp, vp, vp, i32, i32, i32, i32, i32],
+    'mdt_attn_bwd': [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32],
     'mdt_ln_modulate_fwd': [vp, vp, vp, i32, i32, vp, vp, i32, i32],
     'mdt_ln_modulate_bwd': [vp, vp, vp, vp, i32, i32, vp, i32, vp, vp, i32, i32, i32],
     'mdt_ln_modulate_bwd_gate': [vp, vp, vp, vp, i32, i32, vp, i32, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp],
@@ -51,8 +51,8 @@ _PROTOS = {
     'mdt_cast_f32_bf16': [vp, i32, vp, i32, i32, i32, i32],
     'mdt_add_f32': [vp, vp, vp, i64],
     'mdt_silu_bwd': [vp, vp, vp, i64],
-    'mdt_unmask_fwd': [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32],
-    'mdt_unmask_bwd': [vp, vp, i32, vp, vp, i32, i32, i32, i32],
+    'mdt_unmask_fwd': [vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, i32],
+    'mdt_unmask_bwd': [vp, vp, i32, vp, vp, i32, i32, i32, i32, i32],
     'mdt_final_fwd': [vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, i32],
     'mdt_final_bwd': [vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32],
     'mdt_edm_prep': [vp, vp, vp, vp, vp, vp, i32, i32, f32, f32, f32],

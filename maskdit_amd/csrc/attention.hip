@@ -170,7 +170,7 @@ __device__ __forceinline__ float group_max(float v) {
 
 template <int HD, int QF>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
-                                                       float* __restrict__ lse, int L, int H, float scale_log2e) {
+                                                       float* __restrict__ lse, int L, int H, float scale_log2e, int Lv) {
   using C = AttnCfg<HD>;
   __shared__ __attribute__((aligned(16))) char smem[2 * C::TILE_BYTES];
   char* Ks = smem;
@@ -229,7 +229,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
       for (int f = 0; f < 4; ++f)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          s[qi][f][r] *= scale_log2e;
+          // keys >= Lv are padding rows (kept-token count rounded up to the 64-row tile): no probability mass
+          s[qi][f][r] = (kb + 16 * f + 4 * g + r < Lv) ? s[qi][f][r] * scale_log2e : -1e30f;
           mx = fmaxf(mx, s[qi][f][r]);
         }
       mx = group_max(mx);
@@ -289,7 +290,7 @@ template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                           const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                           float* __restrict__ delta, bf16* __restrict__ dqkv, int L,
-                                                          int H, float scale, float scale_log2e) {
+                                                          int H, float scale, float scale_log2e, int Lv) {
   using C = AttnCfg<HD>;
   __shared__ __attribute__((aligned(16))) char smem[2 * C::TILE_BYTES];
   char* Ks = smem;
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float pv = exp2f(s[r] * scale_log2e - my_lse);
+        float pv = (kb + 16 * f + 4 * g + r < Lv) ? exp2f(s[r] * scale_log2e - my_lse) : 0.f;
         ds[f][r] = pv * (dp[r] - dl) * scale;
       }
     }
@@ -379,7 +380,7 @@ template <int HD>
 __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
                                                            const float* __restrict__ lse, const float* __restrict__ delta,
                                                            bf16* __restrict__ dqkv, int L, int H, float scale,
-                                                           float scale_log2e) {
+                                                           float scale_log2e, int Lv) {
   using C = AttnCfg<HD>;
   __shared__ __attribute__((aligned(16))) char smem[2 * C::TILE_BYTES + 512];
   char* Qs = smem;
@@ -443,7 +444,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
       f32x4 dl = *(const f32x4*)(del_s + 16 * f + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float pv = exp2f(s[r] * scale_log2e - ls[r]);
+        float pv = (k0 + i16 < Lv) ? exp2f(s[r] * scale_log2e - ls[r]) : 0.f;  // this lane's key column
         pm[f][r] = pv;
         ds[f][r] = pv * (dp[r] - dl[r]) * scale;
       }
@@ -487,10 +488,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
     default: mdt_set_error("attention: head_dim must be one of 32, 64, 72, 80"); return MDT_ERR_ARG; \
   }
 
-extern "C" int mdt_attn_fwd(const mdt_bf16* qkv, mdt_bf16* out, float* lse, int B, int L, int H, int hd,
+extern "C" int mdt_attn_fwd(const mdt_bf16* qkv, mdt_bf16* out, float* lse, int B, int L, int H, int hd, int L_valid,
                             mdt_stream_t stream) {
   MDT_REQUIRE(qkv && out && lse, "attn_fwd: null pointer");
   MDT_REQUIRE(B > 0 && H > 0 && L > 0 && L % 64 == 0, "attn_fwd: L must be a positive multiple of 64");
+  if (L_valid <= 0 || L_valid > L) L_valid = L;
   float sl = (1.0f / sqrtf((float)hd)) * 1.4426950408889634f;
   // two query fragments per wave pay off for the narrow heads (hd <= 64: -8..-10 %); at hd 72/80 the
   // extra registers cost occupancy and the kernel is bound by its 144-byte-segment global reads anyway
@@ -498,28 +500,30 @@ extern "C" int mdt_attn_fwd(const mdt_bf16* qkv, mdt_bf16* out, float* lse, int 
   if (L % 128 == 0 && (qf_knob == 2 || (qf_knob == 0 && hd <= 64))) {
     dim3 grid(L / 128, B * H);
     ATTN_DISPATCH(hd, hipLaunchKernelGGL((attn_fwd_kernel<HDc, 2>), grid, dim3(256), 0, (hipStream_t)stream,
-                                         (const bf16*)qkv, (bf16*)out, lse, L, H, sl));
+                                         (const bf16*)qkv, (bf16*)out, lse, L, H, sl, L_valid));
   } else {
     dim3 grid(L / 64, B * H);
     ATTN_DISPATCH(hd, hipLaunchKernelGGL((attn_fwd_kernel<HDc, 1>), grid, dim3(256), 0, (hipStream_t)stream,
-                                         (const bf16*)qkv, (bf16*)out, lse, L, H, sl));
+                                         (const bf16*)qkv, (bf16*)out, lse, L, H, sl, L_valid));
   }
   return mdt_check_launch("attn_fwd");
 }
 
 extern "C" int mdt_attn_bwd(const mdt_bf16* qkv, const mdt_bf16* out, const mdt_bf16* dout, const float* lse,
-                            float* delta, mdt_bf16* dqkv, int B, int L, int H, int hd, mdt_stream_t stream) {
+                            float* delta, mdt_bf16* dqkv, int B, int L, int H, int hd, int L_valid,
+                            mdt_stream_t stream) {
   MDT_REQUIRE(qkv && out && dout && lse && delta && dqkv, "attn_bwd: null pointer");
   MDT_REQUIRE(B > 0 && H > 0 && L > 0 && L % 64 == 0, "attn_bwd: L must be a positive multiple of 64");
+  if (L_valid <= 0 || L_valid > L) L_valid = L;
   float sc = 1.0f / sqrtf((float)hd);
   float sl = sc * 1.4426950408889634f;
   dim3 grid(L / 64, B * H);
   ATTN_DISPATCH(hd, hipLaunchKernelGGL(attn_bwd_dq_kernel<HDc>, grid, dim3(256), 0, (hipStream_t)stream,
                                        (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta,
-                                       (bf16*)dqkv, L, H, sc, sl));
+                                       (bf16*)dqkv, L, H, sc, sl, L_valid));
   int rc = mdt_check_launch("attn_bwd_dq");
   if (rc) return rc;
   ATTN_DISPATCH(hd, hipLaunchKernelGGL(attn_bwd_dkv_kernel<HDc>, grid, dim3(256), 0, (hipStream_t)stream,
-                                       (const bf16*)qkv, (const bf16*)dout, lse, delta, (bf16*)dqkv, L, H, sc, sl));
+                                       (const bf16*)qkv, (const bf16*)dout, lse, delta, (bf16*)dqkv, L, H, sc, sl, L_valid));
   return mdt_check_launch("attn_bwd_dkv");
 }

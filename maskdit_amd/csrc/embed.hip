@@ -148,7 +148,7 @@ __global__ void silu_bwd_kernel(const float* __restrict__ dy, const float* __res
 __global__ __launch_bounds__(256) void unmask_fwd_kernel(const bf16* __restrict__ xdec, const int32_t* __restrict__ restore,
                                                          int ids_ld, const float* __restrict__ mask_token,
                                                          const float* __restrict__ pos, float* __restrict__ out, int B,
-                                                         int T, int L, int Dd) {
+                                                         int T, int L, int Lp, int Dd) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= (long)B * T) return;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void unmask_fwd_kernel(const bf16* __restrict_
     f32x4 pvv = *(const f32x4*)(pr + c);
     f32x4 v;
     if (r < L) {
-      bf16x4 xv = *(const bf16x4*)(xdec + ((long)b * L + r) * Dd + c);
+      bf16x4 xv = *(const bf16x4*)(xdec + ((long)b * Lp + r) * Dd + c);
       v = (f32x4){bf2f(xv[0]), bf2f(xv[1]), bf2f(xv[2]), bf2f(xv[3])};
     } else if (mask_token) {
       v = *(const f32x4*)(mask_token + c);
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void unmask_fwd_kernel(const bf16* __restrict_
 // grid (B, row chunks of 32 over T); thread owns a float4 column quad.
 __global__ __launch_bounds__(256) void unmask_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ shuffle,
                                                          int ids_ld, bf16* __restrict__ dxdec, float* __restrict__ dmask_token,
-                                                         int T, int L, int Dd) {
+                                                         int T, int L, int Lp, int Dd) {
   const int b = blockIdx.x;
   const int r0 = blockIdx.y * 32, r1 = min(r0 + 32, T);
   for (int cq = threadIdx.x; cq * 4 < Dd; cq += 256) {
@@ -187,9 +187,15 @@ __global__ __launch_bounds__(256) void unmask_bwd_kernel(const float* __restrict
         bf16x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = f2bf(g[e]);
-        *(bf16x4*)(dxdec + ((long)b * L + r) * Dd + 4 * cq) = o;
+        *(bf16x4*)(dxdec + ((long)b * Lp + r) * Dd + 4 * cq) = o;
       } else {
         acc[0] += g[0]; acc[1] += g[1]; acc[2] += g[2]; acc[3] += g[3];
+        if (r < Lp) {  // padding row of the encoder (kept count rounded up to 64): no gradient flows into it
+          bf16x4 z;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) z[e] = (bf16)0.f;
+          *(bf16x4*)(dxdec + ((long)b * Lp + r) * Dd + 4 * cq) = z;
+        }
       }
     }
     if (dmask_token && r1 > L) {
@@ -468,21 +474,24 @@ extern "C" int mdt_silu_bwd(const float* dy, const float* x, mdt_bf16* dx, long 
 }
 
 extern "C" int mdt_unmask_fwd(const mdt_bf16* xdec, const int32_t* restore, int ids_ld, const float* mask_token,
-                              const float* pos, float* out, int B, int T, int L, int Dd, mdt_stream_t stream) {
+                              const float* pos, float* out, int B, int T, int L, int Dd, int L_pitch,
+                              mdt_stream_t stream) {
   MDT_REQUIRE(xdec && pos && out, "unmask_fwd: null pointer");
-  MDT_REQUIRE(Dd % 4 == 0 && L <= T, "unmask_fwd: bad shape");
+  if (L_pitch <= 0) L_pitch = L;
+  MDT_REQUIRE(Dd % 4 == 0 && L <= T && L_pitch >= L, "unmask_fwd: bad shape");
   hipLaunchKernelGGL(unmask_fwd_kernel, dim3(cdiv((long)B * T, 4)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16*)xdec, restore, ids_ld, mask_token, pos, out, B, T, L, Dd);
+                     (const bf16*)xdec, restore, ids_ld, mask_token, pos, out, B, T, L, L_pitch, Dd);
   return mdt_check_launch("unmask_fwd");
 }
 
 extern "C" int mdt_unmask_bwd(const float* dout, const int32_t* shuffle, int ids_ld, mdt_bf16* dxdec,
-                              float* dmask_token, int B, int T, int L, int Dd, mdt_stream_t stream) {
+                              float* dmask_token, int B, int T, int L, int Dd, int L_pitch, mdt_stream_t stream) {
   MDT_REQUIRE(dout && dxdec, "unmask_bwd: null pointer");
-  MDT_REQUIRE(Dd % 4 == 0 && L <= T, "unmask_bwd: bad shape");
+  if (L_pitch <= 0) L_pitch = L;
+  MDT_REQUIRE(Dd % 4 == 0 && L <= T && L_pitch >= L && L_pitch <= T, "unmask_bwd: bad shape");
   dim3 grid(B, cdiv(T, 32));
   hipLaunchKernelGGL(unmask_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dout, shuffle, ids_ld, (bf16*)dxdec,
-                     dmask_token, T, L, Dd);
+                     dmask_token, T, L, L_pitch, Dd);
   return mdt_check_launch("unmask_bwd");
 }
 

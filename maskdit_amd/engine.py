@@ -330,9 +330,15 @@ class PassPlan:
         sp = eng.sp
         self.eng, self.B, self.masked, self.train = eng, B, masked, train
         self.T = sp.T
-        self.L = (L if L is not None else sp.T // 2) if masked else sp.T
-        if self.L % 64:
-            raise NotImplementedError(f'kept-token count {self.L} must be a multiple of 64')
+        # Lv = kept tokens per sample (models/maskdit.py:99: int(T * (1 - mask_ratio)), any value that a
+        # mask-ratio schedule produces); the encoder runs on L = Lv rounded up to the 64-row tile: the
+        # padding rows gather (removed) tokens, are masked out as attention KEYS, are skipped by the
+        # un-masking gather, and receive exactly zero gradient (mdt_unmask_bwd), so every other kernel
+        # simply sees L rows per sample.
+        self.Lv = (L if L is not None else sp.T // 2) if masked else sp.T
+        if not (1 <= self.Lv <= sp.T):
+            raise ValueError(f'kept-token count {self.Lv} outside [1, {sp.T}]')
+        self.L = _rup(self.Lv, 64)
         self.Bp = _rup(B, 64)
         self.buf: Dict[str, torch.Tensor] = {}
         self.fwd = Plan()
@@ -406,7 +412,8 @@ class PassPlan:
               2 * T, x0.data_ptr(), B, sp.C, sp.R, sp.patch, L, D)
         xs_e = [x0]
         for i in range(sp.depth):
-            xs_e.append(self._block_fwd(f'model.blocks.{i}', 'e', i, xs_e[-1], mod, sp.mod_off('enc', i), D, sp.heads, L, Me))
+            xs_e.append(self._block_fwd(f'model.blocks.{i}', 'e', i, xs_e[-1], mod, sp.mod_off('enc', i), D, sp.heads, L, Me,
+                                        lvalid=self.Lv))
         # ---------------- decoder layer + unmask ----------------------------------------------
         odl = sp.mod_off('dl')
         xnd = self.b16('xn_dl', Me, D)
@@ -420,7 +427,7 @@ class PassPlan:
         xd0 = self.f32('x_d0', Md, Dd)
         use_mt = self.masked and sp.mae
         f.add('mdt_unmask_fwd', xdec.data_ptr(), (ids32.data_ptr() + 4 * T) if self.masked else None, 2 * T,
-              Pf('model.mask_token') if use_mt else None, eng.dpos.data_ptr(), xd0.data_ptr(), B, T, L, Dd)
+              Pf('model.mask_token') if use_mt else None, eng.dpos.data_ptr(), xd0.data_ptr(), B, T, self.Lv, Dd, L)
         xs_d = [xd0]
         for i in range(sp.ddepth):
             xs_d.append(self._block_fwd(f'model.decoder_blocks.{i}', 'd', i, xs_d[-1], mod, sp.mod_off('dec', i), Dd, sp.dheads, T, Md))
@@ -461,7 +468,7 @@ class PassPlan:
             self._slab(f'dec{i}')
         dxdec = self.b16('dxdec', Me, Dd)
         g.add('mdt_unmask_bwd', dxd.data_ptr(), ids32.data_ptr() if self.masked else None, 2 * T, dxdec.data_ptr(),
-              Gf('model.mask_token') if use_mt else None, B, T, L, Dd)
+              Gf('model.mask_token') if use_mt else None, B, T, self.Lv, Dd, L)
         g.add('mdt_gemm_tn', C.byref(self._k(_tn(dxdec.data_ptr(), Dd, xnd.data_ptr(), D, Me, Dd, D,
                                                Gf('model.decoder_layer.linear.weight'), D))))
         g.add('mdt_colsum_bf16', dxdec.data_ptr(), Dd, Gf('model.decoder_layer.linear.bias'), Me, Dd)
@@ -478,7 +485,7 @@ class PassPlan:
             nxt = self._gate_info(f'model.blocks.{i - 1}', 'e', i - 1, mod, dmod, sp.mod_off('enc', i - 1), D, Gf) \
                 if (i > 0 and FUSE_LN_GATE) else None
             self._block_bwd(f'model.blocks.{i}', 'e', i, xs_e[i], mod, dmod, sp.mod_off('enc', i), D, sp.heads, L, Me, dxe, Gf,
-                            fuse_next=nxt, skip_first_gate=FUSE_LN_GATE)
+                            fuse_next=nxt, skip_first_gate=FUSE_LN_GATE, lvalid=self.Lv)
             self._slab(f'enc{i}')
         g.add('mdt_patch_embed_bwd', xin.data_ptr(), None, dxe.data_ptr(), ids32.data_ptr() if ids32 is not None else None,
               2 * T, Gf('model.x_embedder.proj.weight'), Gf('model.x_embedder.proj.bias'), B, sp.C, sp.R, sp.patch, L, D)
@@ -524,7 +531,7 @@ class PassPlan:
         self.bwd.add_callback(cb)
 
     # ---- one DiT block ---------------------------------------------------------------------
-    def _block_fwd(self, prefix, tag, i, x_in, mod, moff, W, heads, rows, M):
+    def _block_fwd(self, prefix, tag, i, x_in, mod, moff, W, heads, rows, M, lvalid=0):
         """DiTBlock.forward (models/maskdit.py:188-192) as 7 launches."""
         eng, lay, f = self.eng, self.eng.lay, self.fwd
         NM = eng.sp.n_mod
@@ -551,7 +558,7 @@ class PassPlan:
         f.add('mdt_ln_modulate_fwd', x_in.data_ptr(), sh1, sc1, NM, rows, xn1.data_ptr(), st1.data_ptr(), M, W)
         f.add('mdt_gemm_nt', C.byref(self._k(_nt(xn1.data_ptr(), W, Wp('attn.qkv.weight'), W, M, 3 * W, W, bias=Pf('attn.qkv.bias'),
                                                epi=EPI_BF16, out=qkv.data_ptr(), ldo=3 * W))))
-        f.add('mdt_attn_fwd', qkv.data_ptr(), ao.data_ptr(), lse.data_ptr(), B, rows, heads, hd)
+        f.add('mdt_attn_fwd', qkv.data_ptr(), ao.data_ptr(), lse.data_ptr(), B, rows, heads, hd, lvalid)
         # the bf16 copies of the branch outputs (ya, ym) and the pre-activation h are saved for the
         # backward only: inference plans skip those stores (2 of 10 resp. 2 of 4 epilogue bytes / element)
         tr = self.train
@@ -574,7 +581,8 @@ class PassPlan:
         return (ym.data_ptr(), mod.data_ptr() + 4 * (moff + 5 * W), NM, self._ws['dys'].data_ptr(),
                 dmod.data_ptr() + 4 * (moff + 5 * W), NM, Gf(f'{prefix}.mlp.fc2.bias'))
 
-    def _block_bwd(self, prefix, tag, i, x_in, mod, dmod, moff, W, heads, rows, M, dx, Gf, fuse_next=None, skip_first_gate=False):
+    def _block_bwd(self, prefix, tag, i, x_in, mod, dmod, moff, W, heads, rows, M, dx, Gf, fuse_next=None, skip_first_gate=False,
+                   lvalid=0):
         """Backward of DiTBlock: dx (fp32 residual-stream gradient) is updated in place.  The gate
         backward that opens the block is folded into the LayerNorm backward that precedes it in stream
         order (`skip_first_gate`), and the block's last LayerNorm backward carries the next block's
@@ -616,7 +624,7 @@ class PassPlan:
             g.add('mdt_gate_bwd', dxp, ya.data_ptr(), g1, NM, rows, dys, dg1, NM, Gn('attn.proj.bias'), M, W)
         g.add('mdt_gemm_tn', C.byref(K(_tn(dys, W, ao.data_ptr(), W, M, W, W, Gn('attn.proj.weight'), W))))
         g.add('mdt_gemm_nt', C.byref(K(_nt(dys, W, WT('attn.proj.weight'), W, M, W, W, epi=EPI_BF16, out=dao, ldo=W))))
-        g.add('mdt_attn_bwd', qkv.data_ptr(), ao.data_ptr(), dao, lse.data_ptr(), delta, dqkv, B, rows, heads, hd)
+        g.add('mdt_attn_bwd', qkv.data_ptr(), ao.data_ptr(), dao, lse.data_ptr(), delta, dqkv, B, rows, heads, hd, lvalid)
         g.add('mdt_gemm_tn', C.byref(K(_tn(dqkv, 3 * W, xn1.data_ptr(), W, M, 3 * W, W, Gn('attn.qkv.weight'), W))))
         g.add('mdt_colsum_bf16', dqkv, 3 * W, Gn('attn.qkv.bias'), M, 3 * W)
         g.add('mdt_gemm_nt', C.byref(K(_nt(dqkv, 3 * W, WT('attn.qkv.weight'), 3 * W, M, W, 3 * W, epi=EPI_BF16, out=dxn, ldo=W))))

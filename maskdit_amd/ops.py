@@ -65,17 +65,17 @@ def gemm_tn(A, Bm, Cout, n1_valid=0, n2_valid=0, splits=0, N1=None, N2=None):
     return Cout
 
 
-def attn_fwd(qkv, B, L, H, hd):
+def attn_fwd(qkv, B, L, H, hd, L_valid=0):
     out = torch.empty(B * L, H * hd, device=qkv.device, dtype=torch.bfloat16)
     lse = torch.empty(B * H * L, device=qkv.device, dtype=torch.float32)
-    call('mdt_attn_fwd', p(qkv), p(out), p(lse), B, L, H, hd, stream_ptr())
+    call('mdt_attn_fwd', p(qkv), p(out), p(lse), B, L, H, hd, L_valid, stream_ptr())
     return out, lse
 
 
-def attn_bwd(qkv, out, dout, lse, B, L, H, hd):
+def attn_bwd(qkv, out, dout, lse, B, L, H, hd, L_valid=0):
     dqkv = torch.empty_like(qkv)
     delta = torch.empty_like(lse)
-    call('mdt_attn_bwd', p(qkv), p(out), p(dout), p(lse), p(delta), p(dqkv), B, L, H, hd, stream_ptr())
+    call('mdt_attn_bwd', p(qkv), p(out), p(dout), p(lse), p(delta), p(dqkv), B, L, H, hd, L_valid, stream_ptr())
     return dqkv
 
 

@@ -39,5 +39,5 @@ def test_argument_validation_without_gpu(built):
     assert rc != 0 and b'null operand' in built.mdt_last_error()
     rc = built.mdt_mask_sort(1, 4, 100, 50, None, None, None, None, None)
     assert rc != 0 and b'power of two' in built.mdt_last_error()
-    rc = built.mdt_attn_fwd(1, 1, 1, 2, 100, 2, 72, None)
+    rc = built.mdt_attn_fwd(1, 1, 1, 2, 100, 2, 72, 0, None)
     assert rc != 0 and b'multiple of 64' in built.mdt_last_error()

@@ -360,3 +360,36 @@ def test_optimizer_and_model_checkpoint_roundtrip(tmp_path):
             worst = max(worst, d)
             assert d <= 2e-5, (k, d)
     print('resume: max param difference after one more step', worst)
+
+
+@pytest.mark.parametrize('ratio', [0.3, 0.6, 0.9])
+def test_arbitrary_mask_ratio_vs_oracle(golden_dir, ratio):
+    """Mask-ratio schedules (train_utils/helper.py:9-27) produce kept-token counts that are not multiples of
+    the 64-row tile (ratio 0.3 -> 179 of 256 kept, 0.6 -> 102, 0.9 -> 25): the encoder runs on the count rounded up, with
+    the padding rows masked out of attention and cut out of the gradient.  Loss and every parameter
+    gradient against the fp32 oracle at the exact count."""
+    g = _load(golden_dir, 's2_train.npz')
+    cfg, P, net = _build('DiT-S/2', 32, int(g['seed']))
+    images, labels, rnd, noise, mnoise = _inputs(g)
+    B, T = mnoise.shape
+    md = M.get_mask(B, T, ratio, DEV, noise=mnoise.to(DEV))
+    Lv = int(T * (1 - ratio))
+    assert md['ids_keep'].shape[1] == Lv and Lv % 64 != 0
+    net.zero_grad(set_to_none=True)
+    loss = M.Losses['edm']().with_draws(net, images.to(DEV), labels.to(DEV), rnd.to(DEV), noise.to(DEV), md, mae_loss_coef=0.1)
+    loss.mean().backward()
+    ref_md = O.get_mask_from_noise(g['mask_noise'], ratio)
+    assert np.array_equal(md['ids_keep'].cpu().numpy(), ref_md['ids_keep'])
+    mdict = {k: torch.from_numpy(v) for k, v in ref_md.items()}
+    loss_ref, _, grads_ref = O.loss_and_grads(P, cfg, images, labels, rnd, noise, mdict, 0.1)
+    rl = ((loss.detach().cpu() - loss_ref).abs() / loss_ref.abs()).max().item()
+    assert rl <= 3e-2, rl
+    params = dict(net.named_parameters())
+    worst = ('', 0.0)
+    for k, gr in grads_ref.items():
+        num = (params[k].grad.detach().cpu().double() - gr.double()).norm().item()
+        den = gr.double().norm().item()
+        if num / (den + 1e-12) > worst[1]:
+            worst = (k, num / (den + 1e-12))
+        assert num <= 6e-2 * den + 1e-7, f'{k}: grad rel L2 err {num / (den + 1e-12):.3e}'
+    print(f'ratio {ratio}: kept {Lv}, loss rel err {rl:.2e}, worst grad rel err {worst[1]:.2e} ({worst[0]})')

@@ -277,6 +277,30 @@ def test_ln_modulate_fwd_bwd(B_, L, D):
     close(dx2, x.grad, 1e-4, 'ln_mod dx (overwrite)')
 
 
+def test_attention_padded_keys():
+    """L_valid < L: rows >= L_valid are padding -- zero probability as keys; with dout = 0 on them the
+    whole dqkv of those rows is exactly zero and the valid rows match an attention over L_valid tokens."""
+    torch.manual_seed(41)
+    B_, L, H, hd, Lv = 3, 192, 6, 64, 179
+    D = H * hd
+    qkv = bf(torch.randn(B_ * L, 3 * D, device=DEV) * 0.7)
+    out, lse = ops.attn_fwd(qkv, B_, L, H, hd, L_valid=Lv)
+    q, k, v = (t.permute(0, 2, 1, 3).float() for t in qkv.view(B_, L, 3, H, hd).unbind(2))  # [B,H,L,hd]
+    q = q.requires_grad_(True); k = k.requires_grad_(True); v = v.requires_grad_(True)
+    att = (q[:, :, :Lv] @ k[:, :, :Lv].transpose(-1, -2)) * hd ** -0.5
+    ref = att.softmax(-1) @ v[:, :, :Lv]                                                   # [B,H,Lv,hd]
+    got = out.view(B_, L, H, hd).permute(0, 2, 1, 3).float()
+    close(got[:, :, :Lv], ref, 1e-2, 'padded attention fwd (valid rows)')
+    dout = torch.zeros(B_, L, H, hd, device=DEV)
+    dout[:, :Lv] = torch.randn(B_, Lv, H, hd, device=DEV)
+    dqkv = ops.attn_bwd(qkv, out, bf(dout.reshape(B_ * L, D)), lse, B_, L, H, hd, L_valid=Lv)
+    ref.backward(bf(dout[:, :Lv]).float().permute(0, 2, 1, 3))
+    d = dqkv.view(B_, L, 3, H, hd).float()
+    for i, t in enumerate((q, k, v)):
+        close(d[:, :Lv, i].permute(0, 2, 1, 3), t.grad[:, :, :Lv], 2e-2, f'padded attention bwd d{"qkv"[i]}')
+    assert float(d[:, Lv:].abs().max()) == 0.0, 'padding rows must receive exactly zero gradient'
+
+
 def test_ln_modulate_bwd_gate_fused():
     """LayerNorm-modulate backward fused with the backward of the residual gate that fed it ==
     mdt_ln_modulate_bwd followed by mdt_gate_bwd on the updated dx."""
@@ -408,13 +432,13 @@ def test_unmask_fwd_bwd():
     out = torch.empty(B_, T, Dd, device=DEV)
     restore32 = ids32[:, T:]
     call('mdt_unmask_fwd', xdec.data_ptr(), restore32.data_ptr(), 2 * T, mt.data_ptr(), pos.data_ptr(), out.data_ptr(),
-         B_, T, L, Dd, sp())
+         B_, T, L, Dd, 0, sp())
     close(out, ref, 1e-6, 'unmask fwd')
     dout = torch.randn(B_, T, Dd, device=DEV)
     ref.backward(dout)
     dxdec = torch.empty(B_, L, Dd, device=DEV, dtype=torch.bfloat16)
     dmt = torch.zeros(Dd, device=DEV)
-    call('mdt_unmask_bwd', dout.data_ptr(), ids32.data_ptr(), 2 * T, dxdec.data_ptr(), dmt.data_ptr(), B_, T, L, Dd, sp())
+    call('mdt_unmask_bwd', dout.data_ptr(), ids32.data_ptr(), 2 * T, dxdec.data_ptr(), dmt.data_ptr(), B_, T, L, Dd, 0, sp())
     close(dxdec, x32.grad, 1e-2, 'unmask dxdec')
     close(dmt, mt.grad, 1e-4, 'unmask dmask_token')
 
