@@ -21,7 +21,6 @@ Reference semantics: DiT.forward / forward_encoder (models/maskdit.py:467-557), 
 from __future__ import annotations
 
 import ctypes as C
-import math
 import os
 import weakref
 from dataclasses import dataclass

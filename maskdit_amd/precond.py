@@ -13,9 +13,7 @@ calling the module without the library or off-GPU raises.
 """
 from __future__ import annotations
 
-import copy
 import math
-from collections import OrderedDict
 from typing import Dict, Optional
 
 import numpy as np
@@ -24,7 +22,7 @@ import torch.nn as nn
 
 from . import _lib
 from ._lib import call
-from .engine import DEC_HIDDEN, MODEL_CONFIGS, Engine, Spec, make_spec
+from .engine import MODEL_CONFIGS, Engine, Spec, make_spec
 
 
 # ------------------------------------------------------------------------------------------
