@@ -205,6 +205,10 @@ def main():
 
     import maskdit_amd as M
     from maskdit_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH) and local_rank == 0:
+        _lib.build()  # normally prebuilt by __graft_entry__.build(); compiling is not a fallback path
+    if world > 1:
+        dist.barrier()
     lib = _lib.lib()
 
     R = args.resolution
