@@ -47,6 +47,7 @@ LIVE_ENGINES: 'weakref.WeakSet' = weakref.WeakSet()  # lets the optimizer map a 
 # 22 B/element but needs 214 VGPRs (2 waves/SIMD): measured 215 us vs 111 + 46 us for the two separate
 # kernels on XL/2, so the plans use the separate kernels.  Flip to re-measure after a register diet.
 FUSE_LN_GATE = False
+ADA_GROUP = 7  # encoder blocks per adaLN weight-gradient group (XL/2: 4 groups of 7 + the decoder-side group)
 FUSE_COLSUM = os.environ.get('MDT_FUSE_COLSUM', '1') != '0'  # fc1 bias gradient out of the DGELU epilogue (A/B switch)
 
 
@@ -200,7 +201,20 @@ class Layout:
             self.slabs[f'enc{i}'] = span(f'model.blocks.{i}.attn.qkv.weight', f'model.blocks.{i}.mlp.fc2.bias')
         for i in range(sp.ddepth):
             self.slabs[f'dec{i}'] = span(f'model.decoder_blocks.{i}.attn.qkv.weight', f'model.decoder_blocks.{i}.mlp.fc2.bias')
-        self.slabs['ada'] = (0, self.off['model.blocks.0.attn.qkv.weight'])
+        # the stacked adaLN weight [N_mod, D] is 35 % of all gradient bytes: its rows are reduced in groups
+        # whose modulation gradients become final at different points of the backward pass (decoder side
+        # first, then the encoder blocks from the top in groups of ADA_GROUP), not in one piece at the end
+        self.ada_groups: List[Tuple[str, int, int]] = []  # (slab name, first row, end row) in backward order
+        enc_rows = sp.depth * 6 * sp.D
+        self.ada_groups.append(('ada_w_dec', enc_rows, sp.n_mod))
+        hi_blk = sp.depth
+        while hi_blk > 0:
+            lo_blk = max(0, hi_blk - ADA_GROUP)
+            self.ada_groups.append((f'ada_w_enc{lo_blk}', lo_blk * 6 * sp.D, hi_blk * 6 * sp.D))
+            hi_blk = lo_blk
+        for name, r0, r1 in self.ada_groups:
+            self.slabs[name] = (self.ada_w + r0 * sp.D, self.ada_w + r1 * sp.D)
+        self.slabs['ada_b'] = (self.ada_b, self.off['model.blocks.0.attn.qkv.weight'])
         self.slabs['misc'] = (self.off['model.decoder_layer.linear.weight'], self.n)
 
 
@@ -480,23 +494,34 @@ class PassPlan:
         else:
             g.add('mdt_ln_modulate_bwd', ws['dxn'].data_ptr(), xs_e[-1].data_ptr(), st_dl.data_ptr(), mod.data_ptr() + 4 * (odl + D),
                   NM, L, dxe.data_ptr(), 0, dmod.data_ptr() + 4 * odl, dmod.data_ptr() + 4 * (odl + D), NM, Me, D)
+        dmod16 = self.b16('dmod16', Bp, NM)
+
+        def ada_group(name, r0, r1):
+            """modulation columns [r0, r1) are final: bias grads, weight grads of those adaLN rows, slab hook"""
+            n = r1 - r0
+            g.add('mdt_cast_f32_bf16', dmod.data_ptr() + 4 * r0, NM, dmod16.data_ptr() + 2 * r0, NM, B, n, 0)
+            g.add('mdt_colsum_bf16', dmod16.data_ptr() + 2 * r0, NM, Gp + 4 * (lay.ada_b + r0), B, n)
+            g.add('mdt_gemm_tn', C.byref(self._k(_tn(dmod16.data_ptr() + 2 * r0, NM, sc16.data_ptr(), D, Bp, n, D,
+                                                   Gp + 4 * (lay.ada_w + r0 * D), D))))
+            self._slab(name)
+
+        groups = {name: (r0, r1) for name, r0, r1 in lay.ada_groups}
+        ada_group('ada_w_dec', *groups['ada_w_dec'])  # final layer, decoder blocks, decoder layer: all done above
         for i in reversed(range(sp.depth)):
             nxt = self._gate_info(f'model.blocks.{i - 1}', 'e', i - 1, mod, dmod, sp.mod_off('enc', i - 1), D, Gf) \
                 if (i > 0 and FUSE_LN_GATE) else None
             self._block_bwd(f'model.blocks.{i}', 'e', i, xs_e[i], mod, dmod, sp.mod_off('enc', i), D, sp.heads, L, Me, dxe, Gf,
                             fuse_next=nxt, skip_first_gate=FUSE_LN_GATE, lvalid=self.Lv)
             self._slab(f'enc{i}')
+            if f'ada_w_enc{i}' in groups:  # block i is the lowest block of its group
+                ada_group(f'ada_w_enc{i}', *groups[f'ada_w_enc{i}'])
         g.add('mdt_patch_embed_bwd', xin.data_ptr(), None, dxe.data_ptr(), ids32.data_ptr() if ids32 is not None else None,
               2 * T, Gf('model.x_embedder.proj.weight'), Gf('model.x_embedder.proj.bias'), B, sp.C, sp.R, sp.patch, L, D)
         # ---- conditioning path backward ------------------------------------------------------
-        dmod16 = self.b16('dmod16', Bp, NM)
         dsc = self.f32('dsc', Bp, D)
         dc16 = self.b16('dc16', Bp, D)
         dh1 = self.b16('dh1', Bp, D)
-        g.add('mdt_cast_f32_bf16', dmod.data_ptr(), NM, dmod16.data_ptr(), NM, B, NM, 0)
-        g.add('mdt_colsum_bf16', dmod16.data_ptr(), NM, Gp + 4 * lay.ada_b, B, NM)
-        g.add('mdt_gemm_tn', C.byref(self._k(_tn(dmod16.data_ptr(), NM, sc16.data_ptr(), D, Bp, NM, D, Gp + 4 * lay.ada_w, D))))
-        self._slab('ada')
+        self._slab('ada_b')  # every group has written its part of the stacked adaLN bias gradient
         # M = batch, N = D, K = every modulation output (221 k on XL/2): split the contraction
         g.add('mdt_gemm_nt', C.byref(self._k(_nt(dmod16.data_ptr(), NM, WT('ada'), NM, B, D, NM, epi=EPI_F32,
                                                outf=dsc.data_ptr(), ldof=D,

@@ -32,7 +32,14 @@ class FakeEngine:
 
     def backward_order(self):
         sp = self.lay.sp
-        names = [f'dec{i}' for i in reversed(range(sp.ddepth))] + [f'enc{i}' for i in reversed(range(sp.depth))] + ['ada', 'misc']
+        groups = {name for name, _, _ in self.lay.ada_groups}
+        names = [f'dec{i}' for i in reversed(range(sp.ddepth))] + ['ada_w_dec']
+        for i in reversed(range(sp.depth)):
+            names.append(f'enc{i}')
+            if f'ada_w_enc{i}' in groups:
+                names.append(f'ada_w_enc{i}')
+        names += ['ada_b', 'misc']
+        assert set(names) == set(self.lay.slabs)
         return [(n,) + self.lay.slabs[n] for n in names]
 
     def fake_backward(self, rank, step):
