@@ -143,3 +143,19 @@ def test_gemm_nt8_drain_counts():
             w = drain_count(d, nf, rpp)
             landed = set(seq[:len(seq) - w]) if w else set(seq)
             assert all(a in landed for a in awaited), (nf, d, w)
+
+
+def test_bench_cpu_baseline_is_bounded():
+    """bench.py's CPU leg (the oracle's training step in a child process) returns a rate within its
+    wall-clock budget, and gives up cleanly -- instead of stalling the benchmark -- when it cannot."""
+    import importlib.util
+    import time
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    t0 = time.time()
+    r = bench.cpu_baseline(4, 'DiT-S/2', 32, budget_s=120)
+    assert r['kind'] == 'port' and r['unit'] == 'img/s' and r['value'] and r['value'] > 0 and time.time() - t0 < 125
+    t0 = time.time()
+    r2 = bench.cpu_baseline(16, 'DiT-XL/2', 32, budget_s=3)
+    assert r2['value'] is None and time.time() - t0 < 15
