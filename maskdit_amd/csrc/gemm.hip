@@ -276,17 +276,33 @@ extern "C" int mdt_gemm_nt(const mdt_gemm_nt_args* a, mdt_stream_t stream) {
   p.k_splits = 1;
   p.group_m = mdt_get_tuning_int(MDT_TUNE_NT8_GROUP_M);
   p.colsum = a->colsum;
-  // large aligned problems: phase-pipelined persistent kernels (gemm_nt8.hip).  variant 0 = auto:
+  // large aligned problems: phase-pipelined persistent kernels (gemm_nt8_impl.h).  variant 0 = auto:
   // 256-row tiles, one 8-wave workgroup per CU (measured best inside the training step); M % 256 != 0
-  // falls to 128-row tiles with two 4-wave workgroups per CU (epilogue of one overlaps the K loop of
-  // the other; +2..5 % on K <= 1152 micro-benchmarks, -7 % at K >= 2048); 2 / 3 force either form.
+  // falls to 128-row tiles with two 4-wave workgroups per CU; 2 / 3 force either form.
   const int variant = mdt_get_tuning_int(MDT_TUNE_GEMM_NT_VARIANT);
-  if (variant != 1 && a->k_splits <= 1 && a->M % 128 == 0 && a->K % 128 == 0) {
+  // the nt8 epilogues work on whole 16-byte pieces straight from the accumulators
+  bool nt8_ok = variant != 1 && a->k_splits <= 1 && a->M % 128 == 0 && a->K % 128 == 0;
+  if (a->out) nt8_ok = nt8_ok && a->ldo % 8 == 0 && ((uintptr_t)a->out & 15) == 0;
+  if (a->out2) nt8_ok = nt8_ok && a->ldo2 % 8 == 0 && ((uintptr_t)a->out2 & 15) == 0;
+  if (a->outf) nt8_ok = nt8_ok && a->ldof % 4 == 0 && ((uintptr_t)a->outf & 15) == 0;
+  if (a->bias) nt8_ok = nt8_ok && ((uintptr_t)a->bias & 15) == 0;
+  if (a->colsum) nt8_ok = nt8_ok && (a->epi == MDT_EPI_BF16 || a->epi == MDT_EPI_DGELU || a->epi == MDT_EPI_DSILU);
+  if (a->epi == MDT_EPI_F32) nt8_ok = nt8_ok && a->out == nullptr;
+  if (a->epi == MDT_EPI_GATE_RES)
+    nt8_ok = nt8_ok && a->rows_per_sample % 64 == 0 && a->ldres % 4 == 0 && a->gate_ld % 4 == 0 &&
+             (((uintptr_t)a->res | (uintptr_t)a->gate) & 15) == 0;
+  if (a->epi == MDT_EPI_DGELU || a->epi == MDT_EPI_DSILU) nt8_ok = nt8_ok && a->ldaux % 4 == 0 && ((uintptr_t)a->aux & 7) == 0;
+  if (nt8_ok) {
     if (mdt_get_tuning_int(MDT_TUNE_NT8_SKIP_EPILOGUE)) p.epi |= 0x100;
     if (mdt_get_tuning_int(MDT_TUNE_NT8_STAGGER)) p.epi |= 0x200;
     const bool can8 = (a->M % 256 == 0);
-    const int cus = 256;
-    const int nf8 = (a->N % 256 == 0) ? 4 : (a->N % 192 == 0) ? 3 : 2;
+    const int cus = nt8_num_cus();
+    // column tile: 256 (NF = 4) where the epilogue class has it, else 192, else 128; "nt8_nf3" prefers 192-column
+    // tiles whenever N allows (no register spill, deeper epilogue look-ahead; A/B knob)
+    const int max_nf = nt8_max_nf(a->epi);
+    const bool prefer3 = mdt_get_tuning_int(MDT_TUNE_NT8_NF3) != 0;
+    int nf8 = (a->N % 256 == 0 && max_nf >= 4) ? 4 : (a->N % 192 == 0) ? 3 : 2;
+    if (prefer3 && a->N % 192 == 0) nf8 = 3;
     const int nf4 = (a->N % 192 == 0) ? 3 : 2;
     const long tiles8 = can8 ? (long)(a->M / 256) * (a->N / (64 * nf8)) : 0;
     const long tiles4 = (long)(a->M / 128) * (a->N / (64 * nf4));
@@ -296,9 +312,9 @@ extern "C" int mdt_gemm_nt(const mdt_gemm_nt_args* a, mdt_stream_t stream) {
       // Cost model (tools/gemm_bench.py --small-m / default): time ~ output area walked by the busiest CU.
       // 8-wave: whole rounds of 256 x 64*nf8 tiles.  4-wave: half-height tiles, two per CU at a time; a
       // workgroup that is alone on its CU (odd tail) runs ~1.6x faster.  With equal areas the 8-wave form
-      // wins inside the training step (607 vs 686 ms at M = 131072: next-tile prefetch under the fused
-      // epilogues, more operand reuse), so the 4-wave form is taken only when whole-tile rounds quantise
-      // badly -- per-GPU batch 128 of the 8-GPU configuration: 685 vs 766 ms per 1024 samples.
+      // wins inside the training step (next-tile prefetch under the fused epilogues, more operand reuse), so
+      // the 4-wave form is taken only when whole-tile rounds quantise badly -- per-GPU batch 128 of the 8-GPU
+      // configuration.
       double w8 = 1e30, w4 = 1e30;
       if (can8 && tiles8 >= 192) w8 = (double)((tiles8 + cus - 1) / cus) * (64.0 * nf8);
       if (tiles4 >= 384) {

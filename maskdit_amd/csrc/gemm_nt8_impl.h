@@ -1,0 +1,569 @@
+// gemm_nt8: the large-problem bf16 NT GEMM (C[M,N] = A[M,K] * B[N,K]^T + fused epilogue).
+//
+// 256 x (64*NF) output tile per 512-thread workgroup (8 waves as 2(M) x 4(N); each wave owns
+// 128 x 16*NF = 8 x NF MFMA 16x16x32 fragments), K-step 64, ONE workgroup per CU.
+// Pipeline (per K-tile 4 phases, one raw s_barrier each, no vmcnt(0) in steady state):
+//
+//   * operands go HBM -> LDS by 16-byte LDS-DMA (global_load_lds) into a 2-stage ring; the ring
+//     is managed at SLOT granularity: A slot p = the 2 x 32 tile rows the two wave-rows consume
+//     in phase p (exactly one LDS-DMA instruction per wave), B = NF instructions per wave.
+//     A slot is refilled with K-tile t+2 in the phase right after its last ds_read retired, so
+//     every load has ~6 phases (1.5 K-tiles of MFMA work) to land;
+//   * phase g: [ds_read the fragments of phase g+1 into the alternate register set]
+//              [LDS-DMA refill of the slot read during phase g-1]  [4*NF MFMAs of phase g]
+//              s_waitcnt vmcnt(W_p) lgkmcnt(0) ; s_barrier
+//     W_p = number of loads issued after the one that the NEXT phase's reads depend on (loads
+//     retire in order), computed at compile time -- never 0 until the last two K-tiles;
+//   * XOR-swizzled LDS image through the *source* address (LDS-DMA destinations are lane-linear),
+//     conflict-free ds_read_b128 fragment reads; XCD-aware tile order;
+//   * PERSISTENT: one workgroup per CU walks the tile list; when a tile's K loop ends, the first
+//     two K-tiles of the workgroup's NEXT output tile are put in flight before the epilogue runs;
+//   * EPILOGUE (round 2): the MFMAs are issued with the operands SWAPPED (D^T = B A^T), so a lane's four
+//     accumulator registers of a fragment are four CONSECUTIVE COLUMNS of one output row (row = lane & 15,
+//     columns 4*(lane>>4)..+3): the fused epilogue works straight out of the accumulators with 16-byte fp32 /
+//     8-byte bf16 global accesses (bf16 pairs of fragments are widened to 16 bytes with v_permlane16_swap) --
+//     no LDS restaging, no barrier, no LDS region.  The epilogue class is a TEMPLATE parameter and every
+//     global load of the tile (residual / saved pre-activation, gates, bias) is issued up front (a
+//     DEPTH-band look-ahead bounded by the register file), so the tile pays ONE memory round trip and its
+//     stores stream out back to back instead of one load->store round trip per 16-row band.
+//
+// Requirements (checked by the dispatcher in gemm.hip): M % (128*WR) == 0, N % (64*NF) == 0,
+// K % 128 == 0, 16-byte aligned rows of every output.  Everything else runs the 128x128 kernel in gemm.hip.
+#pragma once
+#include "common.h"
+#include "../../include/maskdit_hip.h"
+#include "gemm_common.h"
+#include <type_traits>
+
+// an all-zero row standing in for a NULL bias (the epilogue's loads are unconditional)
+#define NT8_ZERO_ROW 1024
+static __device__ float nt8_zero_row[NT8_ZERO_ROW + 64];  // zero-initialised; one copy per translation unit
+
+namespace nt8 {
+
+enum { E_PLAIN = 0, E_F32 = 1, E_ACT = 2, E_GATE = 3, E_DACT = 4 };
+
+// loads issued per wave in phase p: one A slot + RPP B rounds while p < NF (RPP = 1 with 8 waves,
+// 2 with 4 waves: half as many waves share the same B tile)
+constexpr int c_issue(int p, int NF, int RPP) { return 1 + (p < NF ? RPP : 0); }
+
+// steady-state vmcnt operand at the end of phase p (see header)
+constexpr int wait_count(int p, int NF, int RPP) {
+  // next phase (g+1) prefetches A slot (p+2)&3 [of the current or the next K-tile], issued at
+  // phase g-6 whose phase index is (p+2)&3; the B instruction of that phase was issued after it.
+  int w = (((p + 2) & 3) < NF) ? RPP : 0;
+  for (int d = 5; d >= 0; --d) w += c_issue(((p - d) % 4 + 4) % 4, NF, RPP);
+  if (p == 2) {
+    // phase 3 also reads the whole next-tile B: its last instruction was issued at phase NF-1 of
+    // the previous K-tile; after it: one A load per phase NF..3, then phases 0..2 of this tile
+    int wb = (4 - NF) + c_issue(0, NF, RPP) + c_issue(1, NF, RPP) + c_issue(2, NF, RPP);
+    if (wb < w) w = wb;
+  }
+  return w;
+}
+
+// vmcnt operand at the end of phase d (0..7) of the LAST pair of K-tiles, where nothing is issued any
+// more: the steady-state count minus the loads those phases would have issued
+constexpr int drain_count(int d, int NF, int RPP) {
+  if (d >= 6) return 0;  // nothing left to fetch: only LDS reads remain
+  int w = (((d + 2) & 3) < NF) ? RPP : 0;                        // B issued right after the awaited A load (phase -6+d)
+  for (int e = d - 5; e < 0; ++e) w += c_issue(((e % 4) + 4) % 4, NF, RPP);  // steady phases after it
+  if (d == 2) {
+    int wb = 4 - NF;  // A loads issued after the last B instruction of the final K-tile
+    if (wb < w) w = wb;
+  }
+  return w;
+}
+
+// s_waitcnt vmcnt(N) lgkmcnt(0) as the BUILTIN (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8]
+// | vmcnt_hi[15:14]) so that hipcc's own waitcnt bookkeeping sees the LDS reads as retired and
+// does not re-wait (lgkmcnt(0)) in front of the next phase's MFMAs; the empty asm statements pin
+// the memory-operation order around it.
+template <int N> __device__ __forceinline__ void wait_vm_lgkm() {
+  static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
+  asm volatile("" ::: "memory");
+}
+
+// identity that hipcc cannot see through: keeps (uniform base) + (32-bit lane offset) address expressions in the
+// saddr + voffset form instead of one 64-bit vector address per access
+__device__ __forceinline__ unsigned opaque(unsigned v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  bf16x2 t;
+  t[0] = f2bf(lo);
+  t[1] = f2bf(hi);
+  return __builtin_bit_cast(unsigned, t);
+}
+__device__ __forceinline__ f32x4 round_bf16(f32x4 v) {
+  return (f32x4){bf2f(f2bf(v[0])), bf2f(f2bf(v[1])), bf2f(f2bf(v[2])), bf2f(f2bf(v[3]))};
+}
+__device__ __forceinline__ f32x4 unpack_bf16x4(uint2 u) {
+  bf16x2 a = __builtin_bit_cast(bf16x2, u.x), b = __builtin_bit_cast(bf16x2, u.y);
+  return (f32x4){bf2f(a[0]), bf2f(a[1]), bf2f(b[0]), bf2f(b[1])};
+}
+
+// Store one 16-row band of a wave's tile as bf16.  y[j] = this lane's 4 consecutive columns of fragment j
+// (columns 16j + 4g .. +3 of row `fr`, g = lane >> 4).  `ub` = wave-uniform address of the band's first row at
+// the wave tile's column 0; `lo_pair` / `lo_tail` = this lane's byte offsets (bf16_lane_offsets).  Fragment pairs
+// (j, j+1) are exchanged between the odd and even 16-lane rows with v_permlane16_swap so that every lane stores
+// 8 consecutive columns (16 bytes): even g -> fragment j columns 4g..4g+7, odd g -> fragment j+1 columns
+// 4(g-1)..4(g-1)+7.
+template <int NF> __device__ __forceinline__ void store_band_bf16(char* ub, unsigned lo_pair, unsigned lo_tail, const f32x4* y) {
+  unsigned lo[NF], hi[NF];
+#pragma unroll
+  for (int j = 0; j < NF; ++j) {
+    lo[j] = pack_bf16x2(y[j][0], y[j][1]);
+    hi[j] = pack_bf16x2(y[j][2], y[j][3]);
+  }
+#pragma unroll
+  for (int j = 0; j + 1 < NF; j += 2) {
+    auto a = __builtin_amdgcn_permlane16_swap(lo[j], lo[j + 1], false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(hi[j], hi[j + 1], false, false);
+    *(uint4*)(ub + opaque(lo_pair) + 32 * j) = make_uint4(a[0], b[0], a[1], b[1]);
+  }
+  if (NF & 1) *(uint2*)(ub + opaque(lo_tail) + 32 * (NF - 1)) = make_uint2(lo[NF - 1], hi[NF - 1]);
+}
+// lane byte offsets into a bf16 [rows, ld] array for store_band_bf16 (fr = lane & 15, fg = lane >> 4)
+__device__ __forceinline__ unsigned bf16_pair_offset(int fr, int fg, int ld) {
+  return (unsigned)(fr * ld + ((fg & 1) ? 16 + 4 * (fg - 1) : 4 * fg)) * 2u;
+}
+__device__ __forceinline__ unsigned bf16_tail_offset(int fr, int fg, int ld) { return (unsigned)(fr * ld + 4 * fg) * 2u; }
+
+// look-ahead (in 16-row bands) of the epilogue's row-dependent loads: as deep as the register file allows
+constexpr int epi_depth(int E, int NF) {
+  return E == E_DACT ? (NF >= 4 ? 4 : 8) : 0;
+}
+
+}  // namespace nt8
+
+// WR = wave rows: 2 -> 256-row tile, 8 waves, one workgroup per CU (next-tile prefetch under the
+// epilogue); 1 -> 128-row tile, 4 waves, TWO independent workgroups per CU, so one workgroup's
+// epilogue (an HBM-write burst with idle matrix cores) runs under the other's K loop.
+template <int NF, int WR, int E>
+__global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
+  using namespace nt8;
+  constexpr int BN8 = 64 * NF;
+  constexpr int BM8 = 128 * WR;
+  constexpr int RPP = 2 / WR;            // B LDS-DMA rounds per phase
+  constexpr int BROWS = 32 * WR;         // B rows covered by one round (8 rows per wave)
+  constexpr int A_BYTES = BM8 * 128;
+  constexpr int STAGE = A_BYTES + BN8 * 128;
+  constexpr int WN = 16 * NF;
+  constexpr int LDS_BYTES = 2 * STAGE;
+  static_assert(LDS_BYTES * (WR == 2 ? 1 : 2) <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+
+  const int tiles_m = p.M / BM8, tiles_n = p.N / BN8;
+  const int ntiles = tiles_m * tiles_n;
+  int vt = blockIdx.x;  // virtual tile id of this workgroup's current tile (stride gridDim.x)
+  int tm, tn;
+  const int group_m = p.group_m > 0 ? p.group_m : GROUP_M;
+  tile_coords(xcd_remap(vt, ntiles), tiles_m, tiles_n, tm, tn, group_m);
+  int m0 = tm * BM8, n0 = tn * BN8;
+
+  // ---- LDS-DMA addressing.  One wave-instruction = 8 tile rows x 128 B; lane -> (row lane/8,
+  // LDS chunk lane%8); the global chunk is XOR-swizzled with (row & 7) = lane/8.
+  const int lr = lane >> 3, gch = (lane & 7) ^ lr;
+  // A slot q: wave w covers tile rows (w>>2)*128 + 32q + 8(w&3) .. +7.  Addresses are kept as a wave-UNIFORM
+  // 64-bit base (scalar registers, re-pointed per tile, advanced with scalar adds) plus one 32-bit per-lane byte
+  // offset, so the LDS-DMA instructions take the (saddr + voffset) form and the K loop carries no 64-bit
+  // vector address arithmetic.
+  const int a_row0 = (wave >> 2) * 128 + 8 * (wave & 3);
+  const char* a_u = (const char*)(p.A + (long)(m0 + a_row0) * p.lda);  // re-pointed per tile
+  // B round j: wave w covers tile rows BROWS*j + 8w .. +7
+  const char* b_u = (const char*)(p.B + (long)(n0 + 8 * wave) * p.ldb);
+  // per-lane byte offsets of every slot / round (32-bit): the only vector address state of the K loop
+  unsigned a_lo[4], b_lo[NF * RPP];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) a_lo[q] = (unsigned)((lr + 32 * q) * p.lda + gch * 8) * 2u;
+#pragma unroll
+  for (int j = 0; j < NF * RPP; ++j) b_lo[j] = (unsigned)((lr + BROWS * j) * p.ldb + gch * 8) * 2u;
+  const int a_lds0 = a_row0 * 128;           // + 32q*128 + stage*STAGE
+  const int b_lds0 = A_BYTES + wave * 1024;  // + j*8192 + stage*STAGE
+
+  auto issue = [&](int stage, int kt, int ph) {
+    char* base = smem + stage * STAGE;
+    // the empty asm makes a lane offset opaque at every use: hipcc would otherwise fold it into a per-lane
+    // 64-bit base once and carry vector addresses (and their 64-bit adds) through the K loop
+    glds16(a_u + (long)kt * 128 + opaque(a_lo[ph]), base + a_lds0 + ph * 4096);
+    if (ph < NF) {
+#pragma unroll
+      for (int r = 0; r < RPP; ++r) {
+        glds16(b_u + (long)kt * 128 + opaque(b_lo[ph * RPP + r]), base + b_lds0 + (ph * RPP + r) * (BROWS * 128));
+      }
+    }
+  };
+
+  // ---- fragment read offsets (bytes inside a stage); row & 7 == fr & 7 for every fragment
+  const int fr = lane & 15, fg = lane >> 4;
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int sw = ((ks * 4 + fg) ^ (fr & 7)) << 4;
+    a_off[ks] = (wr * 128 + fr) * 128 + sw;
+    b_off[ks] = A_BYTES + (wc * 16 * NF + fr) * 128 + sw;
+  }
+
+  f32x4 acc[8][NF];
+
+  // B fragments are double-buffered across K-tiles while the register file allows it (NF <= 3);
+  // for NF = 4 the next tile's B replaces the current one inside phase 3, ks by ks.
+  constexpr bool BDB = NF < 4;
+  bf16x8 Ar[2][2][2];                // [set][frag in phase][ks]
+  bf16x8 Br[BDB ? 2 : 1][NF][2];     // [set][frag][ks]
+
+  const int nk = p.K >> 6;  // even, >= 2
+
+  // bias of the wave's columns (4 consecutive per fragment).  Loaded unconditionally (a conditional load is
+  // waited for with vmcnt(0) on the spot; no bias = a zero row) at the START of a tile where the register file
+  // allows (NF <= 3), so the epilogue finds it in registers; for NF = 4 at the start of the epilogue.
+  constexpr bool EARLY_BIAS = NF < 4;
+  f32x4 bias[NF];
+  auto load_bias = [&](int c0) {
+    const char* bp = p.bias ? (const char*)(p.bias + c0) : (const char*)(nt8_zero_row + (c0 & (NT8_ZERO_ROW - 1)));
+    const unsigned lo_b = 16u * fg;
+#pragma unroll
+    for (int j = 0; j < NF; ++j) bias[j] = *(const f32x4*)(bp + opaque(lo_b) + 64 * j);
+  };
+
+  // ---- optional stagger (p.epi bit 9): every other workgroup starts half a tile period late so that
+  // the epilogues (HBM bursts with idle matrix cores) of one half of the chip fall under the K
+  // loops of the other half instead of all 256 CUs bursting in lock-step.
+  if ((p.epi & 0x200) && (WR == 1 ? (blockIdx.x >= (gridDim.x >> 1)) : ((blockIdx.x & 8) != 0))) {
+    // 4-wave form: the second workgroup of each CU (dispatched in the second half of the grid)
+    const int naps = ((p.K >> 6) * 1700 + 6000) >> 13;  // ~0.7 us per K-tile + half an epilogue, in 8192-cycle naps
+    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+  // ---- prologue of the first tile: K-tiles 0 and 1 in steady-state issue order
+#pragma unroll
+  for (int ph = 0; ph < 4; ++ph) issue(0, 0, ph);
+#pragma unroll
+  for (int ph = 0; ph < 4; ++ph) issue(1, 1, ph);
+
+  for (;;) {  // persistent tile loop
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < NF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // the two K-tiles of this output tile were put in flight before the previous tile's epilogue
+  // (or just above): everything older -- including that epilogue's stores -- must have retired
+  wait_vm_lgkm<0>();
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  // (returns in order right behind the two prefetched K-tiles; the counted waits of the K loop stay valid --
+  // they only become marginally stricter for the first phases)
+  if constexpr (EARLY_BIAS) load_bias(n0 + wc * WN);
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) Ar[0][i][ks] = *(const bf16x8*)(smem + a_off[ks] + i * 2048);
+#pragma unroll
+    for (int j = 0; j < NF; ++j) Br[0][j][ks] = *(const bf16x8*)(smem + b_off[ks] + j * 2048);
+  }
+
+  // NOTE the operand order of the MFMA: (B fragment, A fragment) -> the accumulator holds the TRANSPOSED
+  // 16x16 block: register r of lane l = C[row = l & 15][col = 4 * (l >> 4) + r].
+#define PAIR_BODY(DRAIN)                                                                              \
+  _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                            \
+    const char* cur = smem + half * STAGE;                                                            \
+    const char* nxt = smem + (half ^ 1) * STAGE;                                                      \
+    _Pragma("unroll") for (int ph = 0; ph < 4; ++ph) {                                                \
+      /* (1) prefetch the fragments of the next phase */                                              \
+      if (ph < 3) {                                                                                   \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
+          Ar[(ph + 1) & 1][i][ks] = *(const bf16x8*)(cur + a_off[ks] + (2 * (ph + 1) + i) * 2048);    \
+      } else if (!(DRAIN && half == 1)) {                                                             \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                            \
+          _Pragma("unroll") for (int i = 0; i < 2; ++i)                                               \
+            Ar[0][i][ks] = *(const bf16x8*)(nxt + a_off[ks] + i * 2048);                              \
+          if (BDB) {                                                                                  \
+            _Pragma("unroll") for (int j = 0; j < NF; ++j)                                            \
+              Br[BDB ? (half ^ 1) : 0][j][ks] = *(const bf16x8*)(nxt + b_off[ks] + j * 2048);         \
+          }                                                                                           \
+        }                                                                                             \
+      }                                                                                               \
+      /* (2) refill the slot whose reads retired before the previous barrier */                       \
+      if (!DRAIN) issue(half, kt + half + 2, ph);                                                     \
+      /* (3) this phase's MFMAs */                                                                    \
+      __builtin_amdgcn_s_setprio(1);                                                                  \
+      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                              \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                \
+          acc[2 * ph + i][j] = mfma16(Br[BDB ? half : 0][j][ks], Ar[ph & 1][i][ks], acc[2 * ph + i][j]); \
+        if (!BDB && ph == 3 && !(DRAIN && half == 1)) {                                               \
+          _Pragma("unroll") for (int j = 0; j < NF; ++j)                                              \
+            Br[0][j][ks] = *(const bf16x8*)(nxt + b_off[ks] + j * 2048);                              \
+        }                                                                                             \
+      }                                                                                               \
+      __builtin_amdgcn_s_setprio(0);                                                                  \
+      /* (4) publish: my share of the next phase's data has landed, my LDS reads have retired */      \
+      if (DRAIN) {                                                                                    \
+        if (half == 0 && ph == 0) wait_vm_lgkm<drain_count(0, NF, RPP)>();                            \
+        else if (half == 0 && ph == 1) wait_vm_lgkm<drain_count(1, NF, RPP)>();                       \
+        else if (half == 0 && ph == 2) wait_vm_lgkm<drain_count(2, NF, RPP)>();                       \
+        else if (half == 0 && ph == 3) wait_vm_lgkm<drain_count(3, NF, RPP)>();                       \
+        else if (half == 1 && ph == 0) wait_vm_lgkm<drain_count(4, NF, RPP)>();                       \
+        else if (half == 1 && ph == 1) wait_vm_lgkm<drain_count(5, NF, RPP)>();                       \
+        else wait_vm_lgkm<0>();                                                                       \
+      }                                                                                               \
+      else if (ph == 0) wait_vm_lgkm<wait_count(0, NF, RPP)>();                                       \
+      else if (ph == 1) wait_vm_lgkm<wait_count(1, NF, RPP)>();                                       \
+      else if (ph == 2) wait_vm_lgkm<wait_count(2, NF, RPP)>();                                       \
+      else wait_vm_lgkm<wait_count(3, NF, RPP)>();                                                    \
+      __builtin_amdgcn_s_barrier();                                                                   \
+      asm volatile("" ::: "memory");                                                                  \
+    }                                                                                                 \
+  }
+
+  int kt = 0;
+  for (; kt + 2 < nk; kt += 2) { PAIR_BODY(false) }
+  { PAIR_BODY(true) }
+#undef PAIR_BODY
+
+  // ---- next tile: put its first two K-tiles in flight (every LDS read of this tile retired
+  // before the last barrier), then run this tile's epilogue underneath them
+  const int em0 = m0 + wr * 128, en0 = n0 + wc * WN;  // origin of this wave's 128 x WN block
+  vt += gridDim.x;
+  const bool more = vt < ntiles;
+  if (more) {
+    tile_coords(xcd_remap(vt, ntiles), tiles_m, tiles_n, tm, tn, group_m);
+    m0 = tm * BM8;
+    n0 = tn * BN8;
+    a_u = (const char*)(p.A + (long)(m0 + a_row0) * p.lda);
+    b_u = (const char*)(p.B + (long)(n0 + 8 * wave) * p.ldb);
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) issue(0, 0, ph);
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) issue(1, 1, ph);
+  }
+
+  if (p.epi & 0x100) {  // benchmarking aid (mdt_set_tuning "nt8_skip_epilogue"): main loop only
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < NF; ++j) asm volatile("" ::"v"(acc[i][j]));
+    if (!more) break;
+    continue;
+  }
+
+  // ---- epilogue, straight out of the accumulators: this lane owns rows em0 + 16 i + fr (i = 0..7) and
+  // columns en0 + 16 j + 4 fg .. +3 (j < NF).  Band i = the 16 rows of accumulator row-fragment i.
+  // * Addresses = wave-uniform 64-bit base (scalar; + 16 i rows per band) + ONE 32-bit lane offset per array
+  //   + an immediate: the epilogue holds a handful of address registers instead of one pair per access.
+  // * Run-time options (optional outputs, column sums, which activation) select between straight-line bodies
+  //   (generic lambdas over compile-time tags): no band contains a branch, hipcc counts vmcnt exactly and the
+  //   stores of a tile are issued back to back.
+  // * Every load of the tile is issued before the first use (sched_barrier): ONE memory round trip per tile.
+  auto ubase = [&](const void* base, int ld, int es) { return (char*)base + ((long)em0 * ld + en0) * es; };
+  auto band = [&](char* ub, int i, int ld, int es) { return ub + (long)i * 16 * ld * es; };
+  if constexpr (!EARLY_BIAS) load_bias(en0);
+  if constexpr (E == E_GATE) {
+    // the bias goes into the accumulators before anything is loaded, so its registers are free for the
+    // residual look-ahead
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < NF; ++j) acc[i][j] += bias[j];
+#pragma unroll
+    for (int j = 0; j < NF; ++j) bias[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const int act = p.epi & 0xff;
+  using T = std::true_type;
+  using F = std::false_type;
+
+  auto flush_colsum = [&](const f32x4* csum) {
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float s = csum[j][c];
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 8, 64);
+        if (fr == 0) atomic_add_f32(p.colsum + en0 + 4 * fg + 16 * j + c, s);
+      }
+  };
+
+  if constexpr (E == E_PLAIN) {
+    auto body = [&](auto cs) {
+      constexpr bool CS = decltype(cs)::value;
+      f32x4 csum[NF];
+#pragma unroll
+      for (int j = 0; j < NF; ++j) csum[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      char* ob = ubase(p.out, p.ldo, 2);
+      const unsigned lp = bf16_pair_offset(fr, fg, p.ldo), lt = bf16_tail_offset(fr, fg, p.ldo);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        f32x4 y[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) y[j] = acc[i][j] + bias[j];
+        store_band_bf16<NF>(band(ob, i, p.ldo, 2), lp, lt, y);
+        if (CS) {
+#pragma unroll
+          for (int j = 0; j < NF; ++j) csum[j] += round_bf16(y[j]);
+        }
+      }
+      if (CS) flush_colsum(csum);
+    };
+    if (p.colsum) body(T{}); else body(F{});
+  } else if constexpr (E == E_F32) {  // outf = acc + bias (the dispatcher sends "also bf16" requests elsewhere)
+    char* fb = ubase(p.outf, p.ldof, 4);
+    const unsigned lf = (unsigned)(fr * p.ldof + 4 * fg) * 4u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < NF; ++j) *(f32x4*)(band(fb, i, p.ldof, 4) + opaque(lf) + 64 * j) = acc[i][j] + bias[j];
+  } else if constexpr (E == E_ACT) {
+    // out = h = bf16(acc + bias) (optional), out2 = bf16(act(h))
+    auto body = [&](auto keep_h, auto is_gelu) {
+      constexpr bool KH = decltype(keep_h)::value, GELU = decltype(is_gelu)::value;
+      char* hb = KH ? ubase(p.out, p.ldo, 2) : nullptr;
+      char* ab = ubase(p.out2, p.ldo2, 2);
+      const unsigned hp = bf16_pair_offset(fr, fg, p.ldo), ht = bf16_tail_offset(fr, fg, p.ldo);
+      const unsigned ap = bf16_pair_offset(fr, fg, p.ldo2), at = bf16_tail_offset(fr, fg, p.ldo2);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        f32x4 y[NF], a[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+          y[j] = round_bf16(acc[i][j] + bias[j]);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) a[j][c] = GELU ? gelu_tanh(y[j][c]) : silu(y[j][c]);
+        }
+        if (KH) store_band_bf16<NF>(band(hb, i, p.ldo, 2), hp, ht, y);
+        store_band_bf16<NF>(band(ab, i, p.ldo2, 2), ap, at, a);
+      }
+    };
+    if (act == MDT_EPI_GELU) { if (p.out) body(T{}, T{}); else body(F{}, T{}); }
+    else { if (p.out) body(T{}, F{}); else body(F{}, F{}); }
+  } else if constexpr (E == E_GATE) {
+    // y = bf16(acc + bias) (stored when out != NULL); outf = res + gate[sample] * y.  rows_per_sample % 64 == 0
+    // (dispatcher), so each 64-row half of the wave's block lies in one sample.
+    auto body = [&](auto keep_y, auto two_gates) {
+      constexpr bool KY = decltype(keep_y)::value, G2 = decltype(two_gates)::value;
+      constexpr int D = (NF >= 3) ? (G2 ? 6 : 8) : 8;  // residual look-ahead in bands (register budget)
+      char* rb = ubase(p.res, p.ldres, 4);
+      char* fb = ubase(p.outf, p.ldof, 4);
+      char* yb = KY ? ubase(p.out, p.ldo, 2) : nullptr;
+      const unsigned lr_ = (unsigned)(fr * p.ldres + 4 * fg) * 4u, lf = (unsigned)(fr * p.ldof + 4 * fg) * 4u;
+      const unsigned yp = bf16_pair_offset(fr, fg, p.ldo), yt = bf16_tail_offset(fr, fg, p.ldo);
+      const char* g0 = (const char*)(p.gate + (long)(em0 / p.rows_per_sample) * p.gate_ld + en0);
+      const char* g1 = (const char*)(p.gate + (long)((em0 + 64) / p.rows_per_sample) * p.gate_ld + en0);
+      const unsigned lg = 16u * fg;
+      f32x4 pre[8][NF], gate[G2 ? 2 : 1][NF];
+#pragma unroll
+      for (int i = 0; i < (D < 8 ? D : 8); ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) pre[i][j] = *(const f32x4*)(band(rb, i, p.ldres, 4) + opaque(lr_) + 64 * j);
+#pragma unroll
+      for (int j = 0; j < NF; ++j) {
+        gate[0][j] = *(const f32x4*)(g0 + opaque(lg) + 64 * j);
+        if (G2) gate[G2 ? 1 : 0][j] = *(const f32x4*)(g1 + opaque(lg) + 64 * j);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        f32x4 y[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) y[j] = round_bf16(acc[i][j]);
+        if (i + D < 8) {
+#pragma unroll
+          for (int j = 0; j < NF; ++j) pre[i + D][j] = *(const f32x4*)(band(rb, i + D, p.ldres, 4) + opaque(lr_) + 64 * j);
+        }
+#pragma unroll
+        for (int j = 0; j < NF; ++j) *(f32x4*)(band(fb, i, p.ldof, 4) + opaque(lf) + 64 * j) = pre[i][j] + gate[G2 ? (i >> 2) : 0][j] * y[j];
+        if (KY) store_band_bf16<NF>(band(yb, i, p.ldo, 2), yp, yt, y);
+      }
+    };
+    // rows_per_sample % 128 == 0 (every shipped shape): the wave's 128-row block lies in ONE sample
+    if (p.rows_per_sample % 128 == 0) { if (p.out) body(T{}, F{}); else body(F{}, F{}); }
+    else { if (p.out) body(T{}, T{}); else body(F{}, T{}); }
+  } else {  // E_DACT: out = bf16((acc + bias) * act'(aux)), optional column sums of the stored values
+    auto body = [&](auto cs, auto is_gelu) {
+      constexpr bool CS = decltype(cs)::value, GELU = decltype(is_gelu)::value;
+      constexpr int D = epi_depth(E, NF);
+      char* xb = ubase(p.aux, p.ldaux, 2);
+      char* ob = ubase(p.out, p.ldo, 2);
+      const unsigned lx = bf16_tail_offset(fr, fg, p.ldaux);
+      const unsigned lp = bf16_pair_offset(fr, fg, p.ldo), lt = bf16_tail_offset(fr, fg, p.ldo);
+      uint2 pre[8][NF];
+#pragma unroll
+      for (int i = 0; i < (D < 8 ? D : 8); ++i)
+#pragma unroll
+        for (int j = 0; j < NF; ++j) pre[i][j] = *(const uint2*)(band(xb, i, p.ldaux, 2) + opaque(lx) + 32 * j);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 csum[NF];
+#pragma unroll
+      for (int j = 0; j < NF; ++j) csum[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        f32x4 y[NF];
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+          const f32x4 h = unpack_bf16x4(pre[i][j]);
+          const f32x4 v = acc[i][j] + bias[j];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) y[j][c] = v[c] * (GELU ? gelu_tanh_grad(h[c]) : silu_grad(h[c]));
+        }
+        if (i + D < 8) {
+#pragma unroll
+          for (int j = 0; j < NF; ++j) pre[i + D][j] = *(const uint2*)(band(xb, i + D, p.ldaux, 2) + opaque(lx) + 32 * j);
+        }
+        store_band_bf16<NF>(band(ob, i, p.ldo, 2), lp, lt, y);
+        if (CS) {
+#pragma unroll
+          for (int j = 0; j < NF; ++j) csum[j] += round_bf16(y[j]);
+        }
+      }
+      if (CS) flush_colsum(csum);
+    };
+    if (act == MDT_EPI_DGELU) { if (p.colsum) body(T{}, T{}); else body(F{}, T{}); }
+    else { if (p.colsum) body(T{}, F{}); else body(F{}, F{}); }
+  }
+  if (!more) break;
+  }  // persistent tile loop
+}
+
+int nt8_num_cus();
+
+// one translation unit per epilogue class (gemm_nt8_c<class>.hip: #define NT8_CLASS <0..4>, then include this
+// header and expand NT8_INSTANTIATE_CLASS) -- the five classes compile in parallel
+#define NT8_CAT_(a, b) a##b
+#define NT8_CAT(a, b) NT8_CAT_(a, b)
+#define NT8_INST(NF, WR) template __global__ void gemm_nt8_kernel<NF, WR, NT8_CLASS>(NTParams);
+#define NT8_LAUNCH(NF, WR) hipLaunchKernelGGL((gemm_nt8_kernel<NF, WR, NT8_CLASS>), dim3(grid), blk, 0, stream, p)
+// NT8_WIDE = 1: the class has a 256 x 256 (NF = 4) instantiation (E_GATE keeps a 5-band residual look-ahead in
+// registers next to the accumulators and stops at NF = 3)
+#define NT8_INSTANTIATE_CLASS(NT8_WIDE, NT8_WIDE_INST)                                                            \
+  NT8_INST(2, 2) NT8_INST(3, 2) NT8_INST(2, 1) NT8_INST(3, 1)                                       \
+  NT8_WIDE_INST                                                                                     \
+  int NT8_CAT(launch_gemm_nt8_class, NT8_CLASS)(const NTParams& p, int nf, int wr, hipStream_t stream) { \
+    const int bm = 128 * wr;                                                                        \
+    const int ntiles = (p.M / bm) * (p.N / (64 * nf));                                              \
+    const int slots = nt8_num_cus() * (wr == 1 ? 2 : 1);                                            \
+    const int grid = ntiles < slots ? ntiles : slots;                                               \
+    const dim3 blk(256 * wr);                                                                       \
+    if (nf == 4 && !(NT8_WIDE && wr == 2)) {                                                        \
+      mdt_set_error("gemm_nt8: no 256-column instantiation for this epilogue class");               \
+      return MDT_ERR_ARG;                                                                           \
+    }                                                                                               \
+    if (wr == 2) {                                                                                  \
+      switch (nf) {                                                                                 \
+        case 2: NT8_LAUNCH(2, 2); break;                                                            \
+        case 3: NT8_LAUNCH(3, 2); break;                                                            \
+        default: NT8_LAUNCH((NT8_WIDE ? 4 : 2), 2); break;                                          \
+      }                                                                                             \
+    } else {                                                                                        \
+      if (nf == 3) NT8_LAUNCH(3, 1);                                                                \
+      else NT8_LAUNCH(2, 1);                                                                        \
+    }                                                                                               \
+    return mdt_check_launch("gemm_nt8");                                                            \
+  }

@@ -153,7 +153,7 @@ def gen_train(tag, model_type, R, B, seed, with_grads):
     print(f'{tag}.npz written; loss[:4] =', loss.detach().numpy()[:4])
 
 
-def gen_sampler(tag, model_type, R, seeds, num_steps, cfg_scale, seed):
+def gen_sampler(tag, model_type, R, seeds, num_steps, cfg_scale, seed, nocfg=True):
     cfg = O.make_cfg(model_type, img_resolution=R)
     P = O.init_params(cfg, seed=seed, dezero=True)
     net = build_ref(model_type, R, P)
@@ -166,7 +166,7 @@ def gen_sampler(tag, model_type, R, seeds, num_steps, cfg_scale, seed):
         z = ref_edm_sampler(net, latents.float(), labels.float(), randn_like=rnd.randn_like,
                             cfg_scale=cfg_scale, num_steps=num_steps)
         z_nocfg = ref_edm_sampler(net, latents.float(), labels.float(), randn_like=rnd.randn_like,
-                                  cfg_scale=None, num_steps=num_steps)
+                                  cfg_scale=None, num_steps=num_steps) if nocfg else torch.zeros(0, dtype=torch.float64)
     np.savez_compressed(os.path.join(HERE, f'{tag}.npz'), seed=np.int64(seed), seeds=np.array(seeds),
                         latents=latents.numpy(), cls=cls.numpy(), num_steps=np.int64(num_steps),
                         cfg_scale=np.float64(cfg_scale), z=z.numpy(), z_nocfg=z_nocfg.numpy())
@@ -185,10 +185,21 @@ def gen_moments():
     print('moments.npz written')
 
 
+JOBS = {
+    'mask': gen_mask,
+    'moments': gen_moments,
+    's2_train': lambda: gen_train('s2_train', 'DiT-S/2', 32, 16, seed=0, with_grads=True),       # BASELINE config 1
+    's2_512_fwd': lambda: gen_train('s2_512_fwd', 'DiT-S/2', 64, 2, seed=3, with_grads=False),   # T=1024 / L=512 shapes
+    'xl2_fwd': lambda: gen_train('xl2_fwd', 'DiT-XL/2', 32, 2, seed=4, with_grads=False),        # hd=72 path
+    's2_sampler': lambda: gen_sampler('s2_sampler', 'DiT-S/2', 32, [100, 101, 102, 103], 6, 1.5, seed=2),
+    # round 2: gradients on the BASELINE configs themselves (configs[1]: XL/2 256; configs[3]: T=1024 / L=512)
+    'xl2_train': lambda: gen_train('xl2_train', 'DiT-XL/2', 32, 2, seed=5, with_grads=True),
+    's2_512_train': lambda: gen_train('s2_512_train', 'DiT-S/2', 64, 2, seed=6, with_grads=True),
+    # configs[4]: XL/2, 50 Heun steps, cfg 1.5, the reference's fp32 network (sample.py:30-66)
+    'xl2_sampler': lambda: gen_sampler('xl2_sampler', 'DiT-XL/2', 32, [0, 1], 50, 1.5, seed=7, nocfg=False),
+}
+
 if __name__ == '__main__':
-    gen_mask()
-    gen_moments()
-    gen_train('s2_train', 'DiT-S/2', 32, 16, seed=0, with_grads=True)       # BASELINE config 1
-    gen_train('s2_512_fwd', 'DiT-S/2', 64, 2, seed=3, with_grads=False)     # T=1024 / L=512 shapes
-    gen_train('xl2_fwd', 'DiT-XL/2', 32, 2, seed=4, with_grads=False)       # hd=72 path
-    gen_sampler('s2_sampler', 'DiT-S/2', 32, [100, 101, 102, 103], 6, 1.5, seed=2)
+    # python tests/golden/make_golden.py [job ...]   (no arguments: every fixture)
+    for job in (sys.argv[1:] or list(JOBS)):
+        JOBS[job]()
