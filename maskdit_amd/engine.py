@@ -356,6 +356,7 @@ class PassPlan:
         self.buf: Dict[str, torch.Tensor] = {}
         self.fwd = Plan()
         self.bwd = Plan()
+        self.gen = 0  # forward generation: the saved activations belong to the LAST forward through this plan
         self._build()
 
     # ---- buffers -----------------------------------------------------------------------
@@ -659,10 +660,20 @@ class PassPlan:
             g.add('mdt_ln_modulate_bwd', dxn, x_in.data_ptr(), st1.data_ptr(), sc1, NM, rows, dxp, 1, dsh1, dsc1, NM, M, W)
 
     # ---- execution ---------------------------------------------------------------------------
-    def run_forward(self):
+    def run_forward(self) -> int:
         if self.eng.shadows_dirty:
             self.eng.refresh_shadows()
+        self.gen += 1
         self.fwd.run(torch.cuda.current_stream().cuda_stream)
+        return self.gen
 
-    def run_backward(self):
+    def run_backward(self, gen: Optional[int] = None):
+        """`gen` = the value run_forward returned for the forward being differentiated.  The activations live in
+        this plan's buffers, not in the autograd graph: a later forward of the same shape overwrites them, and a
+        backward of the EARLIER forward would silently differentiate the wrong activations -- so it raises."""
+        if gen is not None and gen != self.gen:
+            raise RuntimeError(
+                'maskdit_amd: backward of a forward whose saved activations were overwritten by a later forward of the '
+                f'same shape (forward #{gen}, buffers now hold #{self.gen}).  Call backward() before the next forward '
+                '(gradient accumulation: one forward/backward per micro-batch), or evaluate under torch.no_grad().')
         self.bwd.run(torch.cuda.current_stream().cuda_stream)

@@ -49,7 +49,7 @@ class _LossFn(torch.autograd.Function):
         call('mdt_edm_prep', ybuf.data_ptr(), rnd_normal.data_ptr(), noise.data_ptr(), coef.data_ptr(), yn.data_ptr(),
              pl.buf['xin'].data_ptr(), B, chw, float(P_mean), float(P_std), float(net.sigma_data), st)
         _fill_plan_inputs(pl, labels, _ids32_from_dict(mask_dict, sp.T, L) if masked else None)
-        pl.run_forward()
+        ctx.gen = pl.run_forward()
         loss = torch.empty(B, device=images.device, dtype=torch.float32)
         mask = mask_dict['mask'].contiguous() if masked else None
         call('mdt_edm_loss_fwd', pl.buf['F'].data_ptr(), yn.data_ptr(), ybuf.data_ptr(), coef.data_ptr(),
@@ -71,7 +71,7 @@ class _LossFn(torch.autograd.Function):
         call('mdt_edm_loss_bwd', dloss.data_ptr(), b['D'].data_ptr(), b['yn'].data_ptr(), b['y'].data_ptr(), b['coef'].data_ptr(),
              ctx.mask.data_ptr() if ctx.mask is not None else None, ctx.mae, b['dF'].data_ptr(), pl.B, sp.C, sp.R, sp.patch,
              _stream())
-        pl.run_backward()
+        pl.run_backward(ctx.gen)
         return (None,) * 11
 
 

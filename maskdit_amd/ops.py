@@ -26,8 +26,9 @@ def _need(t, dtype, name):
 
 
 def gemm_nt(A, Bw, bias=None, epi=EPI_BF16, out=None, out2=None, outf=None, res=None, gate=None, gate_ld=0,
-            rows_per_sample=1, aux=None, M=None, k_splits=0, colsum=None):
-    """C = A[M,K] @ Bw[N,K]^T with a fused epilogue (see include/maskdit_hip.h)."""
+            rows_per_sample=1, aux=None, M=None, k_splits=0, colsum=None, no_out=False):
+    """C = A[M,K] @ Bw[N,K]^T with a fused epilogue (see include/maskdit_hip.h).  `no_out`: leave the OPTIONAL bf16
+    output of MDT_EPI_GELU / SILU / GATE_RES NULL (what the inference plans do)."""
     _need(A, torch.bfloat16, 'A')
     _need(Bw, torch.bfloat16, 'B')
     M = A.shape[0] if M is None else M
@@ -35,7 +36,8 @@ def gemm_nt(A, Bw, bias=None, epi=EPI_BF16, out=None, out2=None, outf=None, res=
     a = GemmNTArgs()
     a.A, a.lda, a.B, a.ldb, a.M, a.N, a.K = p(A), A.stride(0), p(Bw), Bw.stride(0), M, N, K
     a.bias, a.epi = p(bias), epi
-    if epi in (EPI_BF16, EPI_GELU, EPI_SILU, EPI_GATE_RES, EPI_DGELU, EPI_DSILU) and out is None:
+    if epi in (EPI_BF16, EPI_GELU, EPI_SILU, EPI_GATE_RES, EPI_DGELU, EPI_DSILU) and out is None and not (
+            no_out and epi in (EPI_GELU, EPI_SILU, EPI_GATE_RES)):
         out = torch.empty(A.shape[0], N, device=A.device, dtype=torch.bfloat16)
     if epi in (EPI_GELU, EPI_SILU) and out2 is None:
         out2 = torch.empty(A.shape[0], N, device=A.device, dtype=torch.bfloat16)

@@ -85,7 +85,18 @@ def _ids32_from_dict(mask_dict, T: int, L: int) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------
 
 class _Node(nn.Module):
-    """Name-space node so that parameters get the reference's dotted state-dict keys."""
+    """Name-space node so that parameters get the reference's dotted state-dict keys.  Nodes whose children are
+    numbered (`blocks`, `decoder_blocks`, the `mlp` / `adaLN_modulation` Sequentials) index like the reference's
+    ModuleList / Sequential: `model.blocks[3].attn.qkv.weight`."""
+
+    def __getitem__(self, i):
+        return self._modules[str(i if i >= 0 else len(self._modules) + i)]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def __iter__(self):
+        return iter(self._modules.values())
 
 
 def _attach(root: nn.Module, dotted: str, p: nn.Parameter):
@@ -96,6 +107,26 @@ def _attach(root: nn.Module, dotted: str, p: nn.Parameter):
             node.add_module(k, _Node())
         node = node._modules[k]
     node.register_parameter(parts[-1], p)
+
+
+def reference_param_order(spec: Spec):
+    """Names (below `model.`) in the order `parameters()` yields them on the reference DiT."""
+    def block(prefix):
+        return [f'{prefix}.{n}' for n in ('attn.qkv.weight', 'attn.qkv.bias', 'attn.proj.weight', 'attn.proj.bias',
+                                          'mlp.fc1.weight', 'mlp.fc1.bias', 'mlp.fc2.weight', 'mlp.fc2.bias',
+                                          'adaLN_modulation.1.weight', 'adaLN_modulation.1.bias')]
+    names = ['pos_embed', 'decoder_pos_embed'] + (['mask_token'] if spec.mae else [])
+    names += ['x_embedder.proj.weight', 'x_embedder.proj.bias', 't_embedder.mlp.0.weight', 't_embedder.mlp.0.bias',
+              't_embedder.mlp.2.weight', 't_embedder.mlp.2.bias', 'y_embedder.embedding_table.weight']
+    for i in range(spec.depth):
+        names += block(f'blocks.{i}')
+    names += ['decoder_layer.linear.weight', 'decoder_layer.linear.bias', 'decoder_layer.adaLN_modulation.1.weight',
+              'decoder_layer.adaLN_modulation.1.bias']
+    for i in range(spec.ddepth):
+        names += block(f'decoder_blocks.{i}')
+    names += ['final_layer.linear.weight', 'final_layer.linear.bias', 'final_layer.adaLN_modulation.1.weight',
+              'final_layer.adaLN_modulation.1.bias']
+    return names
 
 
 class DiT(nn.Module):
@@ -119,11 +150,17 @@ class DiT(nn.Module):
         self.use_encoder_feat = False
         from .engine import param_table
         T, D, Dd = spec.T, spec.D, spec.Dd
-        _attach(self, 'pos_embed', nn.Parameter(torch.zeros(1, T, D), requires_grad=False))
-        _attach(self, 'decoder_pos_embed', nn.Parameter(torch.zeros(1, T, Dd), requires_grad=False))
-        for name, shp in param_table(spec):
-            assert name.startswith('model.')
-            _attach(self, name[len('model.'):], nn.Parameter(torch.zeros(shp)))
+        # REGISTRATION order = the reference module tree's `parameters()` order (models/maskdit.py:242-330: the
+        # DiT's own parameters pos_embed, decoder_pos_embed, mask_token; then x_embedder, t_embedder, y_embedder,
+        # blocks[i].{attn.qkv, attn.proj, mlp.fc1, mlp.fc2, adaLN_modulation.1}, decoder_layer.{linear, adaLN},
+        # decoder_blocks, final_layer.{linear, adaLN}), because optimizer state dicts are positional
+        # (train.py:141 hands `model.parameters()` to FusedAdam, :153/:264 save / load its state by index).  The
+        # ARENA order (engine.param_table) is independent of it.
+        shapes = {name[len('model.'):]: shp for name, shp in param_table(spec)}
+        shapes['pos_embed'], shapes['decoder_pos_embed'] = (1, T, D), (1, T, Dd)
+        for name in reference_param_order(spec):
+            _attach(self, name, nn.Parameter(torch.zeros(shapes.pop(name)), requires_grad=name not in ('pos_embed', 'decoder_pos_embed')))
+        assert not shapes, f'parameters missing from the registration order: {sorted(shapes)}'
         if not spec.mae:
             self.mask_token = None
         self.initialize_weights()
@@ -217,9 +254,11 @@ class EDMPrecond(nn.Module):
                                            'there is no CPU path')
             self._bind(p0.device)
         eng = self._engine
-        # any in-place torch write to a parameter view (load_state_dict, EMA copy, a foreign
-        # optimizer) bumps the arena's version counter -> bf16 shadows are stale
-        v = eng.P._version + eng.pos._version + eng.dpos._version
+        # any in-place torch write to a parameter (load_state_dict, the reference's update_ema, a foreign
+        # optimizer) bumps THAT parameter's version counter (after `p.data = view` a Parameter keeps its own
+        # counter, the arena's does not move) -> the bf16 / K-major shadows are stale.  The engine's own
+        # optimizer kernel writes the arena and the shadows together and bumps nothing.
+        v = eng.P._version + eng.pos._version + eng.dpos._version + sum(p._version for p in self.parameters())
         if v != self._seen_version:
             eng.shadows_dirty = True
             self._seen_version = v
@@ -337,7 +376,7 @@ class _NetFn(torch.autograd.Function):
         call('mdt_precond_coef', sigma.data_ptr(), coef.data_ptr(), B, float(net.sigma_data), st)
         call('mdt_scale_rows', x.data_ptr(), coef.data_ptr(), 2, pl.buf['xin'].data_ptr(), B, chw, st)
         _fill_plan_inputs(pl, labels, ids32)
-        pl.run_forward()
+        ctx.gen = pl.run_forward()
         D = torch.empty_like(x)
         call('mdt_precond_out', x.data_ptr(), pl.buf['F'].data_ptr(), coef.data_ptr(), D.data_ptr(), B, chw, st)
         ctx.net, ctx.pl = net, pl
@@ -356,7 +395,7 @@ class _NetFn(torch.autograd.Function):
         # D = c_skip x + c_out F  =>  dF = c_out dD   (gradient w.r.t. x is not produced)
         call('mdt_scale_rows', dD.data_ptr(), pl.buf['coef'].data_ptr(), 1, pl.buf['dF'].data_ptr(), B,
              sp.C * sp.R * sp.R, _stream())
-        pl.run_backward()
+        pl.run_backward(ctx.gen)
         return (None,) * 8
 
 

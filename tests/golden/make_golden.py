@@ -185,7 +185,22 @@ def gen_moments():
     print('moments.npz written')
 
 
+def gen_param_order():
+    """`parameters()` order (names + shapes) of the reference module tree: optimizer state dicts are positional
+    (train.py:141,153,264), so a drop-in must register its parameters in the same order."""
+    import json
+    out = {}
+    for mt in ('DiT-S/2', 'DiT-XL/2'):
+        net = ref_m.Precond_models['edm'](img_resolution=32, img_channels=4, num_classes=1000, model_type=mt,
+                                          use_decoder=True, mae_loss_coef=0.1, pad_cls_token=False)
+        out[mt] = [[n, list(p.shape), bool(p.requires_grad)] for n, p in net.named_parameters()]
+    with open(os.path.join(HERE, 'param_order.json'), 'w') as f:
+        json.dump(out, f)
+    print('param_order.json written')
+
+
 JOBS = {
+    'param_order': gen_param_order,
     'mask': gen_mask,
     'moments': gen_moments,
     's2_train': lambda: gen_train('s2_train', 'DiT-S/2', 32, 16, seed=0, with_grads=True),       # BASELINE config 1

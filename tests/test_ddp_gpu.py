@@ -1,7 +1,10 @@
-"""Data-parallel path on the real engine: two ranks (gloo rendezvous, both on cuda:0 -- the GPU box
-has one device, RCCL needs one device per rank) train the same S/2 model on two halves of a batch
-through maskdit_amd.DataParallel; the averaged slab-wise gradients must equal the single-process
-gradients of the full batch, and the replicas must stay bit-identical after the optimizer step."""
+"""Data-parallel path on the real engine: two ranks train the same S/2 model on two halves of a batch through
+maskdit_amd.DataParallel; the averaged slab-wise gradients must equal (a) the fp32 ORACLE's gradients of the full
+batch (bf16-compute tolerance 1e-2 per tensor) and (b) the single-process HIP gradients of the full batch
+(5e-3: same kernels, different tile counts / atomic order), and the replicas must stay bit-identical after the
+optimizer step.  On a one-GPU box both ranks share cuda:0 over a gloo rendezvous (RCCL needs one device per
+rank); with >= 2 visible GPUs the same worker also runs over the 'nccl' backend (= RCCL, the production path:
+ReduceOp.AVG on arena views, collectives on RCCL's stream overlapping the backward kernels)."""
 import os
 import sys
 
@@ -12,16 +15,17 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, backend='gloo'):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    devno = rank if backend == 'nccl' else 0
+    torch.cuda.set_device(devno)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         import maskdit_amd as M
         from oracle import maskdit_oracle as O
-        dev = 'cuda:0'
-        torch.cuda.set_device(0)
+        dev = f'cuda:{devno}'
         cfg = O.make_cfg('DiT-S/2', img_resolution=32)
         P = O.init_params(cfg, seed=rank, dezero=True)  # different replicas: construction must broadcast rank 0's
         net = M.Precond_models['edm'](img_resolution=32, img_channels=4, num_classes=1000, model_type='DiT-S/2',
@@ -54,6 +58,13 @@ def _worker(rank, world, port, q):
         run(half, dp).mean().backward()
         dp.finish_grad_sync()
         g_dp = {k: p.grad.detach().clone() for k, p in net.named_parameters() if p.requires_grad}
+        if rank == 0:  # (a) the averaged gradient IS the full-batch gradient of the fp32 oracle
+            mdict = {k: torch.from_numpy(v) for k, v in O.get_mask_from_noise(mnoise.numpy(), 0.5).items()}
+            _, _, g_ref = O.loss_and_grads(P0, cfg, images, labels, rnd, noise, mdict, 0.1)
+            for k, gr in g_ref.items():
+                num = (g_dp[k].cpu().double() - gr.double()).norm().item()
+                den = gr.double().norm().item()
+                assert num <= 1e-2 * den + 1e-7, f'{k}: DP gradient differs from the oracle ({num / (den + 1e-12):.3e})'
         # single-process reference on the full batch (same weights), no DP hook
         net.engine().grad_slab_hook = None
         opt.zero_grad(set_to_none=True)
@@ -64,7 +75,7 @@ def _worker(rank, world, port, q):
                 num = (p.grad - g_dp[k]).norm().item()
                 den = p.grad.norm().item()
                 worst = max(worst, num / (den + 1e-12))
-                assert num <= 2e-2 * den + 1e-7, f'{k}: DP gradient differs from the full-batch gradient ({num / (den + 1e-12):.3e})'
+                assert num <= 5e-3 * den + 1e-7, f'{k}: DP gradient differs from the full-batch gradient ({num / (den + 1e-12):.3e})'
         # restore the averaged grads, step, and compare replicas bit for bit
         for k, p in net.named_parameters():
             if p.requires_grad:
@@ -82,13 +93,20 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _backends():
+    return ['gloo'] + (['nccl'] if torch.cuda.is_available() and torch.cuda.device_count() >= 2 else [])
+
+
 @pytest.mark.timeout(600)
-def test_two_rank_data_parallel_on_one_gpu():
+@pytest.mark.parametrize('backend', ['gloo', 'nccl'])
+def test_two_rank_data_parallel(backend):
+    if backend not in _backends():
+        pytest.skip('the nccl (RCCL) variant needs >= 2 visible GPUs')
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29700 + (os.getpid() % 1000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29700 + (os.getpid() % 1000) + (7 if backend == 'nccl' else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=500) for _ in procs]

@@ -4,10 +4,13 @@ the C ABI) against (a) the committed golden fixtures produced by running the ref
 
 Tolerances (stated per check): masking / indices bit-exact; the network computes its GEMMs and
 attention in bf16 with fp32 accumulation (BASELINE: "AMP bf16") while the oracle / reference
-fixture is fp32, so latents, losses and gradients are compared at bf16-appropriate tolerances:
-  D_yn, sampler latents : max |err| <= 3e-2 * max |ref|
-  per-sample loss       : rel 3e-2
-  parameter gradients   : per tensor ||g - g_ref||_2 <= 6e-2 * ||g_ref||_2  (+ tiny abs floor)
+fixture is fp32, so latents, losses and gradients are compared at bf16-appropriate tolerances, set at
+<= 3x the worst value measured on MI355X (round 2; round 1 allowed 20x):
+  D_yn (denoised latents, one net evaluation) : max |err| <= TOL_D = 3e-3 * max |ref|    (measured 6e-4 .. 1e-3)
+  per-sample loss                             : rel TOL_LOSS = 1e-3                      (measured 9e-5 .. 3e-4)
+  parameter gradients  : per tensor ||g - g_ref||_2 <= TOL_GRAD = 1e-2 * ||g_ref||_2     (measured 3e-3; + tiny abs floor)
+  multi-step sampler latents (bf16 network vs the reference's fp32 network, error compounds over the
+  Heun steps)                                 : stated at the test
 fp32-only kernels (optimizer, EMA, EDM algebra) : 1e-5 relative.
 """
 import copy
@@ -25,6 +28,7 @@ if torch.cuda.is_available():
     from oracle import maskdit_oracle as O
 
 DEV = 'cuda'
+TOL_D, TOL_LOSS, TOL_GRAD = 3e-3, 1e-3, 1e-2
 
 
 def _load(golden_dir, name):
@@ -79,10 +83,10 @@ def test_forward_loss_vs_reference_fixture(golden_dir, name, model, R):
     D = net.engine().plan(int(g['B']), True, False, md['ids_keep'].shape[1]).buf['D']
     e = _relmax(D, torch.from_numpy(g['D_yn']))
     print(f'[{name}] D_yn rel-to-max err {e:.3e}')
-    assert e <= 3e-2
+    assert e <= TOL_D
     rl = ((loss.cpu() - torch.from_numpy(g['loss'])).abs() / torch.from_numpy(g['loss']).abs()).max().item()
     print(f'[{name}] loss rel err {rl:.3e}')
-    assert rl <= 3e-2
+    assert rl <= TOL_LOSS
 
 
 def test_s2_train_step_vs_oracle_and_fixture(golden_dir):
@@ -105,7 +109,7 @@ def test_s2_train_step_vs_oracle_and_fixture(golden_dir):
     assert torch.allclose(loss_ref, torch.from_numpy(g['loss']), rtol=1e-4, atol=1e-6)  # oracle == reference fixture
     rl = ((loss.detach().cpu() - loss_ref).abs() / loss_ref.abs()).max().item()
     print(f'loss rel err {rl:.3e}')
-    assert rl <= 3e-2
+    assert rl <= TOL_LOSS
     worst = ('', 0.0)
     params = dict(net.named_parameters())
     for k, gr in grads_ref.items():
@@ -116,7 +120,7 @@ def test_s2_train_step_vs_oracle_and_fixture(golden_dir):
         rel = num / (den + 1e-12)
         if rel > worst[1]:
             worst = (k, rel)
-        assert num <= 6e-2 * den + 1e-7, f'{k}: grad rel L2 err {rel:.3e} (|g| = {den:.3e})'
+        assert num <= TOL_GRAD * den + 1e-7, f'{k}: grad rel L2 err {rel:.3e} (|g| = {den:.3e})'
     print(f'worst grad rel L2 err {worst[1]:.3e} at {worst[0]}')
     # ---- optimizer + EMA: fused kernel vs the oracle applied to the HIP gradients (fp32, 1e-5)
     g_hip = {k: params[k].grad.detach().cpu().clone() for k in grads_ref}
@@ -147,6 +151,63 @@ def test_s2_train_step_vs_oracle_and_fixture(golden_dir):
     for k in list(grads_ref)[:8]:
         ref = 0.99 * e_before[k] + 0.01 * params[k].detach().cpu()
         assert torch.allclose(ema_params[k].detach().cpu(), ref, rtol=1e-5, atol=1e-7), k
+
+
+@pytest.mark.parametrize('name,model,R', [('xl2_train.npz', 'DiT-XL/2', 32),      # BASELINE configs[1]: the benched model
+                                          ('s2_512_train.npz', 'DiT-S/2', 64)])   # configs[3] shapes: T = 1024, L = 512
+def test_backward_on_baseline_configs_vs_reference(golden_dir, name, model, R):
+    """Gradient parity ON the BASELINE configurations (round 1 had forward-only fixtures there): XL/2 (hd 72, the
+    NF = 3 GEMM tiles, D = 1152 norm / gate kernels inside real blocks) and 512^2 latents (T = 1024, L = 512
+    attention fwd + bwd).  Loss and D_yn against the reference-generated fixture; EVERY parameter gradient against
+    the fp32 oracle (itself pinned to the same fixture by tests/test_oracle_golden.py) and its L2 norm against the
+    reference's own."""
+    g = _load(golden_dir, name)
+    cfg, P, net = _build(model, R, int(g['seed']))
+    net.zero_grad(set_to_none=True)
+    loss, md = _run_loss(net, g)
+    loss.mean().backward()
+    B = int(g['B'])
+    D = net.engine().plan(B, True, True, md['ids_keep'].shape[1]).buf['D']
+    e = _relmax(D, torch.from_numpy(g['D_yn']))
+    rl = ((loss.detach().cpu() - torch.from_numpy(g['loss'])).abs() / torch.from_numpy(g['loss']).abs()).max().item()
+    print(f'[{name}] D_yn rel-to-max err {e:.3e}, loss rel err {rl:.3e}')
+    assert e <= TOL_D and rl <= TOL_LOSS
+    images, labels, rnd, noise, _ = _inputs(g)
+    mdict = {k: torch.from_numpy(v) for k, v in O.get_mask_from_noise(g['mask_noise'], 0.5).items()}
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    _, _, grads_ref = O.loss_and_grads(P, cfg, images, labels, rnd, noise, mdict, 0.1)
+    params = dict(net.named_parameters())
+    names = [str(n) for n in g['param_names']]
+    worst = ('', 0.0)
+    for i, k in enumerate(names):
+        got = params[k].grad.detach().cpu().double()
+        den = grads_ref[k].double().norm().item()
+        num = (got - grads_ref[k].double()).norm().item()
+        rel = num / (den + 1e-12)
+        if rel > worst[1]:
+            worst = (k, rel)
+        assert num <= TOL_GRAD * den + 1e-7, f'{k}: grad rel L2 err {rel:.3e} (|g| = {den:.3e})'
+        ref_norm = float(g['grad_sums'][i][2])  # the reference's own ||g||_2
+        assert abs(got.norm().item() - ref_norm) <= TOL_GRAD * ref_norm + 1e-7, (k, got.norm().item(), ref_norm)
+    print(f'[{name}] {len(names)} gradients, worst rel L2 err {worst[1]:.3e} at {worst[0]}')
+
+
+def test_xl2_sampler_50_steps_vs_reference_fixture(golden_dir):
+    """BASELINE configs[4] as benchmarked: XL/2, 50 Heun steps (99 network evaluations), cfg 1.5, hipGraph path --
+    against the reference's own edm_sampler output (fp32 network, fp64 state; tests/golden/make_golden.py).
+    This engine evaluates the network in bf16 (deviation from sample.py:56, which runs it in fp32):
+    the test MEASURES that drift after 99 evaluations and bounds it."""
+    g = _load(golden_dir, 'xl2_sampler.npz')
+    cfg, P, net = _build('DiT-XL/2', 32, int(g['seed']), train=False)
+    labels = torch.eye(1000)[torch.from_numpy(g['cls'])].to(DEV)
+    lat = torch.from_numpy(g['latents']).to(DEV)
+    z = M.edm_sampler(net, lat, labels, cfg_scale=float(g['cfg_scale']), num_steps=int(g['num_steps']))
+    ref = torch.from_numpy(g['z'])
+    e = _relmax(z, ref)
+    rms = ((z.cpu() - ref).norm() / ref.norm()).item()
+    print(f'XL/2 50-step sampler (bf16 net) vs reference (fp32 net): rel-to-max err {e:.3e}, rel L2 err {rms:.3e}')
+    assert z.dtype == torch.float64 and bool(torch.isfinite(z).all())
+    assert e <= 2e-2 and rms <= 1e-2
 
 
 def test_generic_net_autograd_path_matches_fused_loss(golden_dir):
@@ -191,15 +252,15 @@ def test_eval_forward_and_cfg_vs_oracle():
     with torch.no_grad():
         D = net(x.to(DEV), sigma.to(DEV), y.to(DEV))['x']
         ref = O.precond_forward(P, cfg, x, sigma, y, training=False)
-        assert _relmax(D, ref) <= 3e-2
+        assert _relmax(D, ref) <= TOL_D
         # scalar sigma broadcast + CFG (sampling call form: positional cfg_scale, sample.py:56)
         D2 = net(x.to(DEV), torch.tensor(2.5, dtype=torch.float64, device=DEV), y.to(DEV), 1.5)['x']
         ref2 = O.precond_forward(P, cfg, x, torch.tensor(2.5), y, cfg_scale=1.5, training=False)
-        assert _relmax(D2, ref2) <= 3e-2
+        assert _relmax(D2, ref2) <= TOL_D
         # eval mode + mask_ratio > 0: mask returned, no masking applied (models/maskdit.py:482)
         out = net(x.to(DEV), sigma.to(DEV), y.to(DEV), mask_ratio=0.5)
         assert 'mask' in out and out['mask'].shape == (3, 256) and out['mask'].sum(1).eq(128).all()
-        assert _relmax(out['x'], ref) <= 3e-2
+        assert _relmax(out['x'], ref) <= TOL_D
 
 
 def test_sampler_vs_reference_fixture(golden_dir):
@@ -212,7 +273,7 @@ def test_sampler_vs_reference_fixture(golden_dir):
     assert z.dtype == torch.float64 and z.shape == lat.shape
     e = _relmax(z, torch.from_numpy(g['z']))
     print(f'sampler (cfg, graph) rel-to-max err {e:.3e}')
-    assert e <= 3e-2
+    assert e <= 5e-3  # 11 bf16 network evaluations compound (measured 1.6e-3)
     z_again = M.edm_sampler(net, lat, labels, cfg_scale=float(g['cfg_scale']), num_steps=n)  # graph replay
     assert torch.equal(z, z_again)
     z_generic = M.edm_sampler(net, lat, labels, cfg_scale=float(g['cfg_scale']), num_steps=n, use_graph=False)
@@ -222,7 +283,7 @@ def test_sampler_vs_reference_fixture(golden_dir):
     z2 = M.edm_sampler(net, lat, labels, cfg_scale=None, num_steps=n)
     e2 = _relmax(z2, torch.from_numpy(g['z_nocfg']))
     print(f'sampler (no cfg) rel-to-max err {e2:.3e}')
-    assert e2 <= 3e-2
+    assert e2 <= 5e-3
 
 
 def test_state_dict_roundtrip_and_rebinding():
@@ -242,8 +303,34 @@ def test_state_dict_roundtrip_and_rebinding():
     with torch.no_grad():
         a = net(x, s)['x'].clone()
         net.model.final_layer.linear.weight.mul_(2.0)
-        b = net(x, s)['x']
-    assert not torch.allclose(a, b)
+        b = net(x, s)['x'].clone()
+        assert not torch.allclose(a, b)
+        # a GEMM weight (read through the bf16 / K-major SHADOWS, not the fp32 master) edited in place AFTER a
+        # forward: `p.mul_` bumps only that Parameter's version counter, not the arena's
+        net.model.blocks[0].attn.qkv.weight.mul_(1.5)
+        c = net(x, s)['x'].clone()
+        assert not torch.allclose(b, c), 'stale bf16 shadow: an in-place parameter edit was not seen'
+        # load_state_dict after a forward (train.py:149 resume; generate.py:49) must take effect as well
+        net.load_state_dict(P, strict=True)
+        d = net(x, s)['x'].clone()
+        ref_net = _build('DiT-S/2', 32, seed=6, train=False)[2]
+        assert torch.equal(d, ref_net(x, s)['x']), 'load_state_dict after a forward left stale shadows'
+
+
+def test_backward_of_an_overwritten_forward_raises(golden_dir):
+    """Activations live in the plan's buffers: two forwards of the same shape followed by a backward through the
+    FIRST one is legal autograd (two losses summed) but would differentiate the second forward's activations --
+    the engine refuses instead of returning a wrong gradient."""
+    g = _load(golden_dir, 's2_train.npz')
+    cfg, P, net = _build('DiT-S/2', 32, int(g['seed']))
+    l1, _ = _run_loss(net, g)
+    l2, _ = _run_loss(net, g)
+    with pytest.raises(RuntimeError, match='overwritten by a later forward'):
+        (l1.mean() + l2.mean()).backward()
+    net.zero_grad(set_to_none=True)
+    l3, _ = _run_loss(net, g)  # the normal order still works afterwards
+    l3.mean().backward()
+    assert net.model.blocks[0].attn.qkv.weight.grad is not None
 
 
 def test_fails_loudly_off_gpu():
@@ -321,7 +408,7 @@ def test_full_size_batch_properties_xl2_bs1024():
         ref, _ = O.edm_loss(P, cfg, images[sl], labels[sl], rnd[sl], noise[sl], mdict, mae_loss_coef=0.1)
     rel = ((full[sl] - ref).abs() / ref.abs()).max().item()
     print(f'XL/2 bs1024: loss vs oracle on 4 samples rel err {rel:.3e}')
-    assert rel <= 3e-2
+    assert rel <= TOL_LOSS
 
 
 def test_optimizer_and_model_checkpoint_roundtrip(tmp_path):
@@ -383,7 +470,7 @@ def test_arbitrary_mask_ratio_vs_oracle(golden_dir, ratio):
     mdict = {k: torch.from_numpy(v) for k, v in ref_md.items()}
     loss_ref, _, grads_ref = O.loss_and_grads(P, cfg, images, labels, rnd, noise, mdict, 0.1)
     rl = ((loss.detach().cpu() - loss_ref).abs() / loss_ref.abs()).max().item()
-    assert rl <= 3e-2, rl
+    assert rl <= TOL_LOSS, rl
     params = dict(net.named_parameters())
     worst = ('', 0.0)
     for k, gr in grads_ref.items():
@@ -391,5 +478,5 @@ def test_arbitrary_mask_ratio_vs_oracle(golden_dir, ratio):
         den = gr.double().norm().item()
         if num / (den + 1e-12) > worst[1]:
             worst = (k, num / (den + 1e-12))
-        assert num <= 6e-2 * den + 1e-7, f'{k}: grad rel L2 err {num / (den + 1e-12):.3e}'
+        assert num <= TOL_GRAD * den + 1e-7, f'{k}: grad rel L2 err {num / (den + 1e-12):.3e}'
     print(f'ratio {ratio}: kept {Lv}, loss rel err {rl:.2e}, worst grad rel err {worst[1]:.2e} ({worst[0]})')

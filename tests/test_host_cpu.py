@@ -159,3 +159,50 @@ def test_bench_cpu_baseline_is_bounded():
     t0 = time.time()
     r2 = bench.cpu_baseline(16, 'DiT-XL/2', 32, budget_s=3)
     assert r2['value'] is None and time.time() - t0 < 15
+
+
+@pytest.mark.parametrize('model', ['DiT-S/2', 'DiT-XL/2'])
+def test_parameter_registration_order_is_the_references(golden_dir, model):
+    """Optimizer state dicts are positional (train.py:141 gives `model.parameters()` to FusedAdam, :153 / :264 load /
+    save its state by index): `parameters()` must enumerate in the reference module tree's order.  Fixture =
+    `named_parameters()` of the reference itself (tests/golden/make_golden.py: param_order)."""
+    import json
+    import maskdit_amd as M
+    with open(os.path.join(golden_dir, 'param_order.json')) as f:
+        ref = json.load(f)[model]
+    if model == 'DiT-XL/2':  # names / shapes / flags only: skip the 2.9 GB of parameter storage
+        from maskdit_amd.engine import make_spec, param_table
+        from maskdit_amd.precond import reference_param_order
+        sp = make_spec(model, 32, 4, 1000)
+        shapes = {n: list(s) for n, s in param_table(sp)}
+        shapes['model.pos_embed'], shapes['model.decoder_pos_embed'] = [1, sp.T, sp.D], [1, sp.T, sp.Dd]
+        got = [['model.' + n, shapes['model.' + n], n not in ('pos_embed', 'decoder_pos_embed')] for n in reference_param_order(sp)]
+    else:
+        net = M.Precond_models['edm'](img_resolution=32, img_channels=4, num_classes=1000, model_type=model,
+                                      use_decoder=True, mae_loss_coef=0.1, pad_cls_token=False)
+        got = [[n, list(p.shape), bool(p.requires_grad)] for n, p in net.named_parameters()]
+    assert got == ref
+
+
+def test_optimizer_state_of_a_reference_checkpoint_maps_by_position(golden_dir):
+    """A reference `opt` state dict (apex layout: param_groups[0]['params'] = 0..N-1 in `model.parameters()` order,
+    state[i] = {exp_avg, exp_avg_sq}; frozen parameters have no entry) restores onto the parameters of the same NAME."""
+    import json
+    import maskdit_amd as M
+    with open(os.path.join(golden_dir, 'param_order.json')) as f:
+        ref = json.load(f)['DiT-S/2']
+    state = {i: {'exp_avg': torch.full(shape, float(i)), 'exp_avg_sq': torch.full(shape, i + 0.5)}
+             for i, (name, shape, rg) in enumerate(ref) if rg}
+    sd = {'state': state, 'param_groups': [{'lr': 3e-4, 'bias_correction': True, 'betas': (0.9, 0.999), 'eps': 1e-8,
+                                           'weight_decay': 0, 'step': 7, 'params': list(range(len(ref)))}]}
+    net = M.Precond_models['edm'](img_resolution=32, img_channels=4, num_classes=1000, model_type='DiT-S/2',
+                                  use_decoder=True, mae_loss_coef=0.1, pad_cls_token=False)
+    opt = M.FusedAdam(net.parameters(), lr=1e-4)
+    opt.load_state_dict(sd)
+    assert opt.param_groups[0]['step'] == 7 and opt.param_groups[0]['lr'] == 3e-4
+    index = {name: i for i, (name, _, _) in enumerate(ref)}
+    for name, p in net.named_parameters():
+        if p.requires_grad:
+            st = opt.state[p]
+            assert float(st['exp_avg'].flatten()[0]) == float(index[name]) and st['exp_avg'].shape == p.shape, name
+            assert float(st['exp_avg_sq'].flatten()[-1]) == index[name] + 0.5, name

@@ -170,50 +170,98 @@ def test_gemm_tn8_pipelined(M, N1, N2):
     assert torch.equal(Cc, B2[:N1].float())
 
 
-@pytest.mark.parametrize('M,N,K', [(256, 256, 128), (512, 384, 256), (1024, 640, 384), (2048, 1152, 1152), (768, 2048, 512)])
+@pytest.mark.parametrize('M,N,K', [(256, 256, 128), (512, 384, 256), (1024, 640, 384), (2048, 1152, 1152), (768, 2048, 512),
+                                   (1536, 4608, 256), (1280, 768, 1152)])
 def test_gemm_nt8_pipelined(M, N, K):
-    """256-row phase-pipelined NT kernel (gemm_nt8.hip) forced on small problems: all three tile
-    widths (NF = 4, 3, 2), 2 .. 18 K-tiles, every fused epilogue; must agree bit for bit with the
-    128x128 kernel (same MFMA order) and with an fp32 matmul within bf16 rounding."""
+    """256-row phase-pipelined NT kernel (gemm_nt8_impl.h) forced on small problems: all three tile widths
+    (NF = 4, 3, 2), 2 .. 18 K-tiles, EVERY epilogue class and run-time option (optional bf16 output present / NULL,
+    column sums, no bias, gate rows changing inside a 128-row block, the prefer-192-column knob); must agree bit for
+    bit with the 128x128 kernel (same MFMA accumulation order; the nt8 epilogue works on the transposed accumulator
+    fragments and widens bf16 stores with v_permlane16_swap -- any lane / column mix-up shows here) and with an fp32
+    matmul within bf16 rounding."""
     torch.manual_seed(22)
     L = 128
     A = bf(torch.randn(M, K, device=DEV) * 0.5)
     W = bf(torch.randn(N, K, device=DEV) * 0.05)
     b = torch.randn(N, device=DEV) * 0.1
     res = torch.randn(M, N, device=DEV)
-    gate = torch.randn(M // L, 2 * N, device=DEV)
+    gate = torch.randn(M // 64, 2 * N, device=DEV)
     aux = bf(torch.randn(M, N, device=DEV))
-    cases = [dict(bias=b, epi=ops.EPI_BF16), dict(bias=b, epi=ops.EPI_F32), dict(bias=b, epi=ops.EPI_GELU),
-             dict(bias=b, epi=ops.EPI_SILU),
-             dict(bias=b, epi=ops.EPI_GATE_RES, res=res, gate=gate[:, N:], gate_ld=2 * N, rows_per_sample=L),
-             dict(bias=None, epi=ops.EPI_DGELU, aux=aux), dict(bias=None, epi=ops.EPI_DSILU, aux=aux)]
+    gr = dict(res=res, gate=gate[:, N:], gate_ld=2 * N)
+    cases = [dict(bias=b, epi=ops.EPI_BF16), dict(bias=None, epi=ops.EPI_BF16, colsum=True), dict(bias=b, epi=ops.EPI_F32),
+             dict(bias=b, epi=ops.EPI_GELU), dict(bias=b, epi=ops.EPI_GELU, no_out=True), dict(bias=None, epi=ops.EPI_SILU),
+             dict(bias=b, epi=ops.EPI_GATE_RES, rows_per_sample=L, **gr),
+             dict(bias=b, epi=ops.EPI_GATE_RES, rows_per_sample=L, no_out=True, **gr),
+             dict(bias=None, epi=ops.EPI_GATE_RES, rows_per_sample=64, **gr),      # gate row changes inside a wave's block
+             dict(bias=b, epi=ops.EPI_GATE_RES, rows_per_sample=192 if M % 192 == 0 else 64, no_out=True, **gr),
+             dict(bias=None, epi=ops.EPI_DGELU, aux=aux), dict(bias=b, epi=ops.EPI_DGELU, aux=aux, colsum=True),
+             dict(bias=None, epi=ops.EPI_DSILU, aux=aux)]
     lib = _lib.lib()
+
+    def run(kw):
+        kw = dict(kw)
+        cs = torch.full((N,), 2.0, device=DEV) if kw.pop('colsum', False) else None
+        outs = ops.gemm_nt(A, W, colsum=cs, **kw)
+        return tuple(outs) + (cs,)
+
     try:
         for kw in cases:
             got = {}
-            for v in (1, 2, 3):  # 128x128 kernel; 8-wave 256-row tiles; 4-wave 128-row tiles (2 workgroups / CU)
+            for v, nf3 in ((1, 0), (2, 0), (3, 0), (2, 1)):  # 128x128; 8-wave 256-row; 4-wave 128-row (2 WG / CU); 8-wave, 192-col pref
                 lib.mdt_set_tuning(b'gemm_nt_variant', v)
-                got[v] = ops.gemm_nt(A, W, **kw)
-            for v in (2, 3):
-                for x, y in zip(got[1], got[v]):
-                    if x is not None:
-                        assert torch.equal(x, y), f'nt8 variant {v} differs from the 128x128 kernel (epi {kw["epi"]})'
+                lib.mdt_set_tuning(b'nt8_nf3', nf3)
+                got[(v, nf3)] = run(kw)
+            for key in ((2, 0), (3, 0), (2, 1)):
+                for idx, (x, y) in enumerate(zip(got[(1, 0)], got[key])):
+                    assert (x is None) == (y is None)
+                    if x is None:
+                        continue
+                    if idx == 3:  # column sums: fp32 atomics in a different order
+                        close(y, x, 1e-5, f'nt8 {key} colsum (epi {kw["epi"]})')
+                    else:
+                        assert torch.equal(x, y), f'nt8 variant {key} output {idx} differs from the 128x128 kernel (case {kw["epi"]}, {sorted(kw)})'
+        lib.mdt_set_tuning(b'nt8_nf3', 0)
         lib.mdt_set_tuning(b'gemm_nt_variant', 3)
         _, _, outf3 = ops.gemm_nt(A, W, b, ops.EPI_F32)
         close(outf3, A.float() @ W.float().t() + b, 1e-5, f'gemm_nt8 4-wave {M}x{N}x{K}')
         lib.mdt_set_tuning(b'gemm_nt_variant', 2)
         _, _, outf = ops.gemm_nt(A, W, b, ops.EPI_F32)
         close(outf, A.float() @ W.float().t() + b, 1e-5, f'gemm_nt8 {M}x{N}x{K}')
-        # A = I with an asymmetric weight: catches transposed / permuted tiles
-        if K == M or True:
-            Ai = torch.zeros(M, K, device=DEV)
-            Ai[torch.arange(min(M, K)), torch.arange(min(M, K))] = 1.0
-            Wa = bf(torch.arange(N, device=DEV)[:, None] * 0.5 + torch.arange(K, device=DEV)[None, :] * 0.001)
-            _, _, o2 = ops.gemm_nt(bf(Ai), Wa, None, ops.EPI_F32)
-            r = min(M, K)
-            assert torch.equal(o2[:r], Wa.float().t()[:r])
+        # A = I with an asymmetric weight: catches transposed / permuted tiles (fp32 and bf16 store paths)
+        Ai = torch.zeros(M, K, device=DEV)
+        Ai[torch.arange(min(M, K)), torch.arange(min(M, K))] = 1.0
+        Wa = bf(torch.arange(N, device=DEV)[:, None] * 0.5 + torch.arange(K, device=DEV)[None, :] * 0.001)
+        o16, _, o2 = ops.gemm_nt(bf(Ai), Wa, None, ops.EPI_F32)
+        r = min(M, K)
+        assert torch.equal(o2[:r], Wa.float().t()[:r])
+        o16, _, _ = ops.gemm_nt(bf(Ai), Wa, None, ops.EPI_BF16)
+        assert torch.equal(o16[:r].float(), bf(Wa.float().t()[:r]).float())
     finally:
         lib.mdt_set_tuning(b'gemm_nt_variant', 0)
+        lib.mdt_set_tuning(b'nt8_nf3', 0)
+
+
+def test_activation_functions_vs_torch():
+    """The sigmoid-form GELU(tanh) / SiLU and their derivatives (hardware exp2 + rcp) against torch fp32 over a dense
+    grid including the tails: |err| <= 2e-6 absolute (they are rounded to bf16, 4e-3 relative, by every caller)."""
+    x = torch.linspace(-12, 12, 128 * 128, device=DEV).view(128, 128)
+    one = bf(torch.eye(128, device=DEV))
+    # route x through the epilogues with an identity GEMM: h = x (bf16-exact grid), out2 = act(h)
+    xb = bf(x)
+    h, a, _ = ops.gemm_nt(one, bf(xb.t().contiguous()), None, ops.EPI_GELU)
+    assert torch.equal(h, xb)
+    close(a, bf(F.gelu(xb.float(), approximate='tanh')), 5e-3, 'gelu_tanh')
+    h, a, _ = ops.gemm_nt(one, bf(xb.t().contiguous()), None, ops.EPI_SILU)
+    close(a, bf(F.silu(xb.float())), 5e-3, 'silu')
+    ones = bf(torch.ones(128, 128, device=DEV) / 128)  # acc = 1 everywhere: out = act'(aux)
+    xg = xb.float().requires_grad_(True)
+    F.gelu(xg, approximate='tanh').sum().backward()
+    o, _, _ = ops.gemm_nt(bf(torch.ones(128, 128, device=DEV)), ones, None, ops.EPI_DGELU, aux=xb)
+    close(o, xg.grad, 5e-3, 'gelu_tanh grad')
+    xg = xb.float().requires_grad_(True)
+    F.silu(xg).sum().backward()
+    o, _, _ = ops.gemm_nt(bf(torch.ones(128, 128, device=DEV)), ones, None, ops.EPI_DSILU, aux=xb)
+    close(o, xg.grad, 5e-3, 'silu grad')
 
 
 def test_gemm_tn_asymmetric_and_edges():
