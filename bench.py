@@ -11,13 +11,25 @@ compute with fp32 master weights, GLOBAL batch 1024 -- as `accum` micro-batches 
 forward + backward + DP gradient all-reduce + fused AdamW + EMA.  Synthetic latents / labels
 are resident in HBM before the timed region.  Prints ONE JSON line (rank 0).
 
+The timed step is train.py:200-230 in full: `sample(moments)` -> class-dropout -> loss forward/backward ->
+(DP gradient mean) -> AdamW -> EMA; the latent MOMENTS [B,8,R,R] and one-hot labels are resident in HBM.
+
 Extra objects in the line:
-  roofline     : the dominant kernel (gemm_nt_kernel, bf16 MFMA): algorithmic FLOPs of its
+  roofline     : the dominant kernel (gemm_nt8_kernel, bf16 MFMA): algorithmic FLOPs of its
                  launches / their summed duration, both measured live with HIP events recorded
                  on the launch stream around every gemm_nt launch of the timed steps.
+                 roofline.encoder = the north-star quantity: XL/2 ENCODER forward + backward (patch-embed ..
+                 28 blocks .. and their backward, incl. the conditioning path) timed with HIP events at the plan
+                 positions engine.PassPlan.marks names; achieved = 350.1 GFLOP/sample / that time.
+                 roofline.traffic = HBM bytes per gemm_nt8 launch from a rocprofv3 --pmc pass of THIS command at
+                 THIS micro-batch (profiles/pmc_gemm_nt.json records the command; null when it does not match).
   cpu_baseline : the CPU oracle (oracle/maskdit_oracle.py, a restatement of the reference
                  path pinned to reference-generated fixtures) timed on this host's cores on a
-                 bounded sample (XL/2, batch 16, fwd+bwd+AdamW+EMA), rank 0, N = 1 only.
+                 bounded sample (XL/2, batch 16, fwd+bwd+AdamW+EMA: >= 3 warm-up + 3 timed steps; thread count
+                 chosen among 32/64/128/all by the warm-up steps and stated) + the 50-step sampler (batch 4,
+                 6 steps timed and scaled by 99/11 network evaluations), rank 0, N = 1 only.
+
+`python bench.py --gpus N` WITHOUT torch.distributed.run re-executes itself under it (one rank per GPU).
 """
 from __future__ import annotations
 
@@ -74,14 +86,24 @@ class GemmTimer:
         self.used += 1
         return e
 
-    def wrap(self, plan):
-        """Replace plan.run by an instrumented replay."""
+    def wrap(self, plan, span=None):
+        """Replace plan.run by an instrumented replay.  span = (first launch index, end index, label): one more
+        event pair around that range of the plan (the encoder)."""
         from maskdit_amd import _lib
         timer = self
         calls = plan.calls
+        if not hasattr(self, 'spans'):
+            self.spans = []
 
         def run(stream):
-            for fn, args, name in calls:
+            for i, (fn, args, name) in enumerate(calls):
+                if span is not None and i == span[0]:
+                    s0 = timer._ev()
+                    timer.lib.mdt_event_record(s0, stream)
+                if span is not None and i == span[1]:
+                    e0 = timer._ev()
+                    timer.lib.mdt_event_record(e0, stream)
+                    timer.spans.append((s0, e0, span[2]))
                 if fn is None:
                     args()
                     continue
@@ -96,8 +118,20 @@ class GemmTimer:
                     rc = fn(*args, stream)
                 if rc != 0:
                     raise _lib.MaskDiTLibError(f'{name} failed ({rc}): {_lib.lib().mdt_last_error().decode()}')
+            if span is not None and span[1] >= len(calls):
+                e0 = timer._ev()
+                timer.lib.mdt_event_record(e0, stream)
+                timer.spans.append((s0, e0, span[2]))
 
         plan.run = run
+
+    def span_ms(self):
+        ms = C.c_float()
+        out = {}
+        for s, e, label in getattr(self, 'spans', []):
+            self.lib.mdt_event_elapsed_ms(s, e, C.byref(ms))
+            out[label] = out.get(label, 0.0) + ms.value
+        return out
 
     def summarise(self):
         ms = C.c_float()
@@ -113,10 +147,10 @@ class GemmTimer:
 _CPU_WORKER = r"""
 import json, sys, time
 sys.path.insert(0, sys.argv[1])
-batch, model, R, threads, out = int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+batch, model, R, out = int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), sys.argv[5]
+cands = [int(c) for c in sys.argv[6].split(',')]
 import torch as T
 from oracle import maskdit_oracle as O
-T.set_num_threads(threads)
 cfg = O.make_cfg(model, img_resolution=R)
 P = O.init_params(cfg, seed=0, dezero=True)
 names = [k for k in P if k not in O.NON_TRAINABLE]
@@ -125,8 +159,8 @@ V = {k: T.zeros_like(P[k]) for k in names}
 EMA = {k: P[k].clone() for k in names}
 g = T.Generator().manual_seed(0)
 Tk = (R // cfg['patch']) ** 2
-times = []
-for it in range(3):
+res = {'warm': [], 'timed': [], 'threads': None, 'sampler': None}
+def one(it):
     images = 0.5 * T.randn(batch, 4, R, R, generator=g)
     labels = T.zeros(batch, 1000)
     labels[T.arange(batch), T.randint(0, 1000, (batch,), generator=g)] = 1
@@ -135,22 +169,47 @@ for it in range(3):
     mnoise = T.rand(batch, Tk, generator=g)
     t0 = time.perf_counter()
     O.train_step(P, Mm, V, EMA, cfg, images, labels, rnd, noise, mnoise, 0.5, 0.1, step=it + 1)
-    times.append(time.perf_counter() - t0)
-    json.dump(times, open(out, 'w'))
+    return time.perf_counter() - t0
+it = 0
+T.set_num_threads(cands[0]); one(it); it += 1          # cold step (page-in, allocator): not recorded
+for c in cands:                                       # warm-up steps double as the thread-count scan
+    T.set_num_threads(c)
+    res['warm'].append((c, one(it))); it += 1
+    json.dump(res, open(out, 'w'))
+while len(res['warm']) < 3:
+    res['warm'].append((cands[0], one(it))); it += 1
+best = min(res['warm'], key=lambda cw: cw[1])[0]
+T.set_num_threads(best)
+res['threads'] = best
+for _ in range(3):
+    res['timed'].append(one(it)); it += 1
+    json.dump(res, open(out, 'w'))
+# sampler leg (BASELINE configs[4] on the CPU): batch 4, cfg 1.5, 6 Heun steps = 11 network evaluations
+sb, ns = 4, 6
+lat = T.randn(sb, 4, R, R, generator=g)
+lab = T.eye(1000)[T.randint(0, 1000, (sb,), generator=g)]
+with T.no_grad():
+    t0 = time.perf_counter()
+    O.edm_sampler(P, cfg, lat, lab, cfg_scale=1.5, num_steps=ns)
+    res['sampler'] = {'seconds': time.perf_counter() - t0, 'batch': sb, 'steps': ns, 'evals': 2 * ns - 1}
+json.dump(res, open(out, 'w'))
 """
 
 
-def cpu_baseline(batch, model, R, budget_s=150.0):
-    """Bounded CPU leg: the oracle's training step (fwd + bwd + AdamW + EMA; oracle/maskdit_oracle.py) in a
-    child process with a wall-clock budget, so that a slow / oversubscribed host can never stall the
-    benchmark (1 warm-up + up to 2 timed steps)."""
+def cpu_baseline(batch, model, R, budget_s=240.0):
+    """Bounded CPU leg (BASELINE.md section 3): the oracle's training step (fwd + bwd + AdamW + EMA;
+    oracle/maskdit_oracle.py) in a child process with a wall-clock budget, so that a slow / oversubscribed host can
+    never stall the benchmark: 1 cold step, >= 3 warm-up steps that also pick the thread count (a 16-sample fp32
+    batch does not scale to all 256 hardware threads of the GPU box: the candidates 32 / 64 / 128 / all are each
+    timed once and the fastest is used and reported), 3 timed steps, then 6 sampler steps."""
     import subprocess
     import tempfile
     cores = os.cpu_count() or 1
-    threads = min(cores, 32)  # fp32 GEMMs of a 16-sample batch stop scaling (and NUMA-thrash) beyond this
+    cands = sorted({min(cores, c) for c in (32, 64, 128, cores)})
     out = tempfile.NamedTemporaryFile(prefix='mdt_cpu_', suffix='.json', delete=False).name
-    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES='')
-    proc = subprocess.Popen([sys.executable, '-c', _CPU_WORKER, ROOT, str(batch), model, str(R), str(threads), out],
+    env = dict(os.environ, HIP_VISIBLE_DEVICES='')
+    env.pop('OMP_NUM_THREADS', None)
+    proc = subprocess.Popen([sys.executable, '-c', _CPU_WORKER, ROOT, str(batch), model, str(R), out, ','.join(map(str, cands))],
                             stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=env)
     try:
         proc.wait(timeout=budget_s)
@@ -158,25 +217,49 @@ def cpu_baseline(batch, model, R, budget_s=150.0):
         proc.kill()
         proc.wait()
     try:
-        times = json.load(open(out))
+        res = json.load(open(out))
     except Exception:
-        times = []
+        res = {'warm': [], 'timed': [], 'threads': None, 'sampler': None}
     finally:
         try:
             os.unlink(out)
         except OSError:
             pass
-    if len(times) >= 2:
-        best = min(times[1:])
-        note = f'1 warm-up + {len(times) - 1} timed, best {best:.2f} s/step'
-    elif len(times) == 1:
-        best = times[0]
-        note = f'only the cold first step fit the {budget_s:.0f} s budget ({best:.2f} s)'
+    scan = ', '.join(f'{c} thr {t:.2f} s' for c, t in res['warm'])
+    if res['timed']:
+        best = min(res['timed'])
+        threads = res['threads']
+        note = f'1 cold + {len(res["warm"])} warm-up (thread scan: {scan}) + {len(res["timed"])} timed steps, best {best:.2f} s/step'
+    elif res['warm']:
+        threads, best = min(res['warm'], key=lambda cw: cw[1])
+        note = f'only {len(res["warm"])} warm-up steps fit the {budget_s:.0f} s budget ({scan})'
     else:
-        return {'value': None, 'unit': 'img/s', 'cores': threads, 'kind': 'port',
+        return {'value': None, 'unit': 'img/s', 'cores': cands[0], 'kind': 'port',
                 'sample': f'{model} latent {R}x{R}, batch {batch}: no step finished within {budget_s:.0f} s'}
-    return {'value': round(batch / best, 3), 'unit': 'img/s', 'cores': threads, 'host_cores': cores, 'kind': 'port',
+    line = {'value': round(batch / best, 3), 'unit': 'img/s', 'cores': threads, 'host_cores': cores, 'kind': 'port',
             'sample': f'{model} latent {R}x{R}, batch {batch}, mask 0.5, fp32 CPU oracle train step (fwd+bwd+AdamW+EMA), {note}'}
+    sm = res.get('sampler')
+    if sm:
+        full = sm['seconds'] * 99.0 / sm['evals']
+        line['sampler'] = {'value': round(sm['batch'] / full, 5), 'unit': 'samples/s', 'cores': threads,
+                           'sample': f'oracle edm_sampler {model}, batch {sm["batch"]}, cfg 1.5: {sm["steps"]} Heun steps '
+                                     f'({sm["evals"]} network evaluations) took {sm["seconds"]:.1f} s, scaled by 99/{sm["evals"]} '
+                                     f'to the 50-step schedule'}
+    return line
+
+
+def respawn_under_torchrun(n):
+    """`python bench.py --gpus N` (N > 1) from a plain shell: re-execute under torch.distributed.run, one rank per
+    GPU of this node (what the driver's launch line does)."""
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    argv = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+            '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, argv)
 
 
 def main():
@@ -186,7 +269,7 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
-            raise SystemExit('bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)')
+            respawn_under_torchrun(args.gpus)  # does not return
         args.gpus = world
     import torch.distributed as dist
     # test hook: MDT_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 over gloo, so that the N > 1 code path
@@ -245,18 +328,22 @@ def main():
             mb //= 2
         accum = per_gpu // mb
 
-    # synthetic data of the dataset's shape, resident in HBM: latents with std = sigma_data,
-    # one-hot labels with class-dropout 0.1 applied (train.py:208-209)
+    # synthetic data of the dataset's shape, resident in HBM: latent MOMENTS [B, 8, R, R] whose sample()
+    # has std = sigma_data (mean 2.745 * randn scaled by 0.18215, logvar -10), one-hot labels
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    x_all = 0.5 * torch.randn(per_gpu, 4, R, R, device=dev, generator=gen)
+    mom_all = torch.cat([2.745 * torch.randn(per_gpu, 4, R, R, device=dev, generator=gen),
+                         torch.full((per_gpu, 4, R, R), -10.0, device=dev)], 1)
     cls = torch.randint(0, 1000, (per_gpu,), device=dev, generator=gen)
-    y_all = torch.zeros(per_gpu, 1000, device=dev)
-    y_all[torch.arange(per_gpu, device=dev), cls] = 1
-    y_all *= (torch.rand(per_gpu, 1, device=dev, generator=gen) >= 0.1).float()
+    y_clean = torch.zeros(per_gpu, 1000, device=dev)
+    y_clean[torch.arange(per_gpu, device=dev), cls] = 1
+    y_all = torch.empty_like(y_clean)
     loss_acc = torch.zeros((), device=dev)
 
     def step():
-        opt.zero_grad(set_to_none=True)
+        x_all = M.sample(mom_all)                 # train.py:203
+        opt.zero_grad(set_to_none=True)           # train.py:206
+        y_all.copy_(y_clean)                      # (the loader hands over fresh labels every step)
+        M.class_dropout_(y_all, 0.1)              # train.py:208-209
         for a in range(accum):
             xs, ys = x_all[a * mb:(a + 1) * mb], y_all[a * mb:(a + 1) * mb]
             last = a == accum - 1
@@ -285,8 +372,8 @@ def main():
     if not args.no_kernel_events:
         timer = GemmTimer(lib)
         pl = net.engine().plan(mb, True, True, None)
-        timer.wrap(pl.fwd)
-        timer.wrap(pl.bwd)
+        timer.wrap(pl.fwd, span=(0, pl.marks['enc_fwd_end'], 'enc_fwd'))
+        timer.wrap(pl.bwd, span=(pl.marks['enc_bwd_begin'], len(pl.bwd.calls), 'enc_bwd'))
     loss_acc.zero_()
     sync()
     t0 = time.perf_counter()
@@ -315,9 +402,22 @@ def main():
             pmc = os.path.join(ROOT, 'profiles', 'pmc_gemm_nt.json')
             if os.path.exists(pmc):
                 try:
-                    roof['traffic'] = json.load(open(pmc)).get('hbm_bytes_per_launch')
+                    rec = json.load(open(pmc))
+                    # only a PMC pass of THIS workload counts (profiles/pmc_gemm_nt.json states its command)
+                    if (rec.get('model'), rec.get('resolution'), rec.get('micro_batch')) == (args.model, R, mb):
+                        roof['traffic'] = rec.get('hbm_bytes_per_launch')
+                        roof['traffic_source'] = rec.get('command')
                 except Exception:
                     pass
+            sp_ms = timer.span_ms()
+            if (args.model, R) == ('DiT-XL/2', 32) and 'enc_fwd' in sp_ms and 'enc_bwd' in sp_ms:
+                enc_ms = (sp_ms['enc_fwd'] + sp_ms['enc_bwd']) / args.steps        # per optimizer step (all micro-batches)
+                enc_tf = 350.1e9 * per_gpu / (enc_ms * 1e-3) / 1e12               # 350.1 GFLOP / sample fwd + bwd
+                roof['encoder'] = {'what': 'XL/2 encoder fwd+bwd (patch-embed, 28 blocks, conditioning path), HIP events',
+                                   'ms': round(enc_ms, 2), 'fwd_ms': round(sp_ms['enc_fwd'] / args.steps, 2),
+                                   'bwd_ms': round(sp_ms['enc_bwd'] / args.steps, 2), 'achieved': round(enc_tf, 1),
+                                   'peak': MFMA_BF16_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(enc_tf / MFMA_BF16_PEAK_TFLOPS, 4),
+                                   'target_frac': 0.60}
 
     # ---- EDM sampler leg (BASELINE configs[4]): XL/2, 50 Heun steps (99 network evaluations of the
     # CFG-doubled batch), cfg_scale 1.5, batch 64, hipGraph-captured; latents only (no VAE).  N = 1 only.
@@ -361,7 +461,7 @@ def main():
             'ms_per_step': round(dt / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'strong',
             'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
             'config': {'workload': f'{args.model} ImageNet{R * 8}-latent [{R}x{R}x4], mask_ratio=0.5, mae_loss_coef=0.1, '
-                                   f'fwd+bwd+grad-allreduce+AdamW+EMA, random-init (de-zeroed) weights',
+                                   f'sample(moments)+class-dropout+fwd+bwd+grad-allreduce+AdamW+EMA, random-init (de-zeroed) weights',
                        'global_batch': args.global_batch, 'per_gpu_batch': per_gpu, 'micro_batch': mb, 'accum': accum,
                        'tokens_per_sample': (R // 2) ** 2, 'kept_tokens': (R // 2) ** 2 // 2, 'parallelism': f'dp{world}'},
             'model_tflops_per_s': round(value * 392.7e9 / 1e12, 1) if (args.model, R) == ('DiT-XL/2', 32) else None,

@@ -18,7 +18,10 @@ int nt8_num_cus() {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
     if (n <= 0) n = 256;
   }
-  return n;
+  // "nt8_max_cus" caps the persistent grid: CUs left free for a concurrent RCCL kernel (data-parallel overlap), and
+  // the half-chip A/B of tools/nt8_bench.py
+  const int cap = mdt_get_tuning_int(MDT_TUNE_NT8_MAX_CUS);
+  return (cap > 0 && cap < n) ? cap : n;
 }
 
 // widest column tile (in 64-column units) the class of epilogue `epi` is instantiated for

@@ -429,6 +429,7 @@ class PassPlan:
             xs_e.append(self._block_fwd(f'model.blocks.{i}', 'e', i, xs_e[-1], mod, sp.mod_off('enc', i), D, sp.heads, L, Me,
                                         lvalid=self.Lv))
         # ---------------- decoder layer + unmask ----------------------------------------------
+        self.marks = {'enc_fwd_end': len(f.calls)}  # launch index where the encoder (+ conditioning path) forward ends
         odl = sp.mod_off('dl')
         xnd = self.b16('xn_dl', Me, D)
         st_dl = self.f32('st_dl', Me, 2)
@@ -508,6 +509,7 @@ class PassPlan:
 
         groups = {name: (r0, r1) for name, r0, r1 in lay.ada_groups}
         ada_group('ada_w_dec', *groups['ada_w_dec'])  # final layer, decoder blocks, decoder layer: all done above
+        self.marks['enc_bwd_begin'] = len(g.calls)  # everything from here on is encoder / conditioning-path backward
         for i in reversed(range(sp.depth)):
             nxt = self._gate_info(f'model.blocks.{i - 1}', 'e', i - 1, mod, dmod, sp.mod_off('enc', i - 1), D, Gf) \
                 if (i > 0 and FUSE_LN_GATE) else None

@@ -156,6 +156,8 @@ def test_bench_cpu_baseline_is_bounded():
     t0 = time.time()
     r = bench.cpu_baseline(4, 'DiT-S/2', 32, budget_s=120)
     assert r['kind'] == 'port' and r['unit'] == 'img/s' and r['value'] and r['value'] > 0 and time.time() - t0 < 125
+    assert '3 timed steps' in r['sample'] and 'warm-up' in r['sample'] and r['cores'] >= 1
+    assert r['sampler']['unit'] == 'samples/s' and r['sampler']['value'] > 0                # the CPU sampler leg
     t0 = time.time()
     r2 = bench.cpu_baseline(16, 'DiT-XL/2', 32, budget_s=3)
     assert r2['value'] is None and time.time() - t0 < 15

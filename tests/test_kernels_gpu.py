@@ -218,6 +218,14 @@ def test_gemm_nt8_pipelined(M, N, K):
                         continue
                     if idx == 3:  # column sums: fp32 atomics in a different order
                         close(y, x, 1e-5, f'nt8 {key} colsum (epi {kw["epi"]})')
+                    elif kw['epi'] in (ops.EPI_DGELU, ops.EPI_DSILU):
+                        # acc * act'(aux): hipcc contracts the product chain into different FMAs in the two kernels, so
+                        # the fp32 value can differ in its last bit and an occasional bf16 rounding flips: at most one
+                        # bf16 ulp (2^-8 relative), on a small fraction of the elements
+                        xf, yf = x.float(), y.float()
+                        bad = xf != yf
+                        assert bad.float().mean().item() < 2e-2, f'nt8 {key} d-activation: {bad.float().mean().item():.3%} elements differ'
+                        assert bool(((xf - yf).abs() <= 2.0 ** -7 * xf.abs().clamp_min(1e-30))[bad].all()), 'more than one bf16 ulp apart'
                     else:
                         assert torch.equal(x, y), f'nt8 variant {key} output {idx} differs from the 128x128 kernel (case {kw["epi"]}, {sorted(kw)})'
         lib.mdt_set_tuning(b'nt8_nf3', 0)

@@ -41,9 +41,10 @@ def main():
         Md = 2 * M
         shapes += [((Md, 1536, 512), 'BF16', 'dec qkv'), ((Md, 512, 512), 'GATE_RES', 'dec proj'), ((Md, 2048, 512), 'GELU', 'dec fc1'),
                    ((Md, 512, 2048), 'GATE_RES', 'dec fc2'), ((Md, 2048, 512), 'DGELU', 'dec fc2 dgrad'), ((Md, 512, 2048), 'BF16', 'dec fc1 dgrad')]
-    variants = [('full', {}), ('no-epi', {'nt8_skip_epilogue': 1}), ('nf3', {'nt8_nf3': 1}), ('stagger', {'nt8_stagger': 1}),
-                ('4-wave', {'gemm_nt_variant': 3})]
-    knobs = ['nt8_skip_epilogue', 'nt8_nf3', 'nt8_stagger', 'gemm_nt_variant']
+    variants = [('full', {}), ('no-epi', {'nt8_skip_epilogue': 1}), ('nf3', {'nt8_nf3': 1}), ('4-wave', {'gemm_nt_variant': 3}),
+                ('4w+stagger', {'gemm_nt_variant': 3, 'nt8_stagger': 1}), ('128 CUs', {'nt8_max_cus': 128}),
+                ('128CU no-epi', {'nt8_max_cus': 128, 'nt8_skip_epilogue': 1})]
+    knobs = ['nt8_skip_epilogue', 'nt8_nf3', 'nt8_stagger', 'gemm_nt_variant', 'nt8_max_cus']
     print(f'{"shape / epilogue":40s} ' + ' '.join(f'{v[0]:>16s}' for v in variants) + '    (TFLOP/s | us)')
     for (m, n, k), name, tag in shapes:
         A = (torch.randn(m, k, device=dev) * 0.5).to(torch.bfloat16)

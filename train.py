@@ -5,10 +5,14 @@
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 train.py --config ...
 
 Same YAML schema, same step body (train.py:200-230: sample -> class dropout -> micro-batches ->
-loss -> backward -> lr warm-up -> optimizer step -> EMA), same checkpoint dict
-({"model","ema","opt","args"} as `{step:07d}.pt`), same throughput log line (steps/sec after a
-device sync every `log_every` steps).  Data: `data.category: synthetic` draws latent moments on the
-device (the LMDB / WebDataset loaders are out of scope, SURVEY.md 8f).  One process per GPU;
+loss -> backward -> lr warm-up -> optimizer step -> EMA), same resume semantics (train.py:147-162,184-188:
+`--ckpt_path` loads model / ema / (strict only) optimizer, the step counter continues from the file name, the
+mask-ratio schedule and the stop condition count from the resume point, and the EMA is initialised from the model
+ONLY on a fresh start), same checkpoint dict ({"model","ema","opt","args"} as `{step:07d}.pt`), same throughput log
+line (steps/sec after a device sync every `log_every` steps).
+
+Data (`data.category`): `synthetic` = latent moments drawn on the device; `wds` / `lmdb` = the reference's latent
+shards / LMDB through maskdit_amd.data (pinned-memory prefetch, H2D on a copy stream).  One process per GPU;
 gradient averaging = maskdit_amd.DataParallel (RCCL), no accelerate / apex / omegaconf needed."""
 from __future__ import annotations
 
@@ -24,24 +28,62 @@ import maskdit_amd as M
 from maskdit_amd.schedule import get_mask_ratio_fn, get_one_hot, load_config, lr_rampup_factor
 
 
-def main():
-    ap = argparse.ArgumentParser()
+def str2bool(v):
+    return str(v).lower() in ('1', 'true', 'yes', 'y', 't')
+
+
+def strip_compile_prefix(sd):
+    """generate.py:46-48: checkpoints written from a torch.compile'd module carry `_orig_mod.` in their keys."""
+    return {k.replace('_orig_mod.', ''): v for k, v in sd.items()}
+
+
+def parse(argv=None):
+    ap = argparse.ArgumentParser('training parameters')
     ap.add_argument('--config', required=True)
     ap.add_argument('--results_dir', default='results')
     ap.add_argument('--exp_name', default='run')
     ap.add_argument('--ckpt_path', default=None)
+    ap.add_argument('--use_strict_load', type=str2bool, default=True)   # train.py:309: False = finetune (weights only, non-strict)
     ap.add_argument('--global_seed', type=int, default=0)
     ap.add_argument('--max_num_steps', type=int, default=None)
-    args = ap.parse_args()
-    cfg = load_config(args.config)
+    ap.add_argument('--data_path', default=None, help='override data.root (wds: shard dir / glob; lmdb: dataset dir)')
+    return ap.parse_args(argv)
 
+
+def make_batches(cfg, args, dev, rank, world, B):
+    """Iterator of (moments [B, 2C, R, R] f32, labels int64 [B]) ON THE DEVICE."""
+    mc = cfg.model
+    R, C = mc.in_size, mc.in_channels
+    cat = cfg.data.get('category', 'synthetic') if 'data' in cfg else 'synthetic'
+    root = args.data_path or (cfg.data.get('root') if 'data' in cfg else None)
+    if cat == 'synthetic':
+        gen = torch.Generator(device=dev).manual_seed(1 + rank)
+
+        def it():
+            while True:
+                mom = torch.cat([2.745 * torch.randn(B, C, R, R, device=dev, generator=gen), torch.full((B, C, R, R), -10.0, device=dev)], 1)
+                yield mom, torch.randint(0, mc.num_classes, (B,), device=dev, generator=gen)
+        return it()
+    from maskdit_amd import data as D
+    if cat in ('wds', 'webdataset', 'imagenet_wds'):
+        src = D.WdsTarLatents(root, B, rank=rank, world=world, seed=args.global_seed, epochs=None)
+    elif cat in ('lmdb', 'imagenet_latent', 'imagenet_lmdb'):
+        src = D.LmdbLatents(root, B, R, rank=rank, world=world, seed=args.global_seed, epochs=None)
+    else:
+        raise ValueError(f'data.category {cat!r}: expected synthetic | wds | lmdb')
+    return D.LatentPrefetcher(src, dev)
+
+
+def train_loop(args):
+    cfg = load_config(args.config)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    if world > 1:
+    if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         dist.init_process_group('nccl', device_id=dev)
     torch.manual_seed(args.global_seed)  # same seed on every rank, as train.py:67-68
 
@@ -54,14 +96,17 @@ def main():
         p.requires_grad_(False)
     opt = M.FusedAdam(net.parameters(), lr=tc.lr, adam_w_mode=True, weight_decay=0)
     step0 = 0
-    if args.ckpt_path:
-        ck = torch.load(args.ckpt_path, map_location='cpu')
-        net.load_state_dict(ck['model'])
-        ema.load_state_dict(ck['ema'])
-        if 'opt' in ck:
+    if args.ckpt_path:  # train.py:147-162
+        ck = torch.load(args.ckpt_path, map_location='cpu', weights_only=False)
+        net.load_state_dict(strip_compile_prefix(ck['model']), strict=args.use_strict_load)
+        ema.load_state_dict(strip_compile_prefix(ck['ema']), strict=args.use_strict_load)
+        if args.use_strict_load and 'opt' in ck:
             opt.load_state_dict(ck['opt'])
-        step0 = int(os.path.basename(args.ckpt_path).split('.')[0]) if os.path.basename(args.ckpt_path)[:7].isdigit() else 0
-    M.update_ema(ema, net, decay=0)  # train.py:188
+        base = os.path.basename(args.ckpt_path).split('.pt')[0]
+        step0 = int(base) if base.isdigit() else 0
+        del ck
+    else:
+        M.update_ema(ema, net, decay=0)  # train.py:184-188: only a FRESH run copies the model into the EMA
     opt.fuse_ema(ema, 0.9999)
     model = M.DataParallel(net) if world > 1 else net
     net.train()
@@ -75,40 +120,36 @@ def main():
     if rank == 0:
         os.makedirs(os.path.join(exp_dir, 'checkpoints'), exist_ok=True)
         print(f'{mc.model_type} params {sum(p.numel() for p in net.parameters()):,}  global batch {global_batch} '
-              f'({world} GPU x {mb} x accum {accum})', flush=True)
+              f'({world} GPU x {mb} x accum {accum})  steps {step0} -> {step0 + max_steps}', flush=True)
 
-    R, C = mc.in_size, mc.in_channels
-    gen = torch.Generator(device=dev).manual_seed(1 + rank)
-
-    def batch():  # (moments [B,2C,R,R], one-hot labels) as the latent datasets yield them (datasets.py:184-192)
-        B = mb * accum
-        mom = torch.cat([2.745 * torch.randn(B, C, R, R, device=dev, generator=gen), torch.full((B, C, R, R), -10.0, device=dev)], 1)
-        return mom, get_one_hot(torch.randint(0, mc.num_classes, (B,), device=dev, generator=gen), mc.num_classes)
-
+    batches = make_batches(cfg, args, dev, rank, world, mb * accum)
     step, log_steps, running = step0, 0, torch.zeros((), device=dev)
+    last_loss = None
     t0 = time.time()
-    while step < max_steps:
-        x, y = batch()
-        x = M.sample(x)                                        # train.py:203
+    for mom, cls in batches:
+        x = M.sample(mom)                                      # train.py:203
+        y = get_one_hot(cls, mc.num_classes)                   # train_wds.py:266 (LMDB labels arrive as class indices too)
         opt.zero_grad(set_to_none=True)                        # train.py:206
-        ratio = mask_ratio_fn(step / max_steps)
-        M.class_dropout_(y, mc.class_dropout_prob)             # train.py:208-209
+        ratio = mask_ratio_fn((step - step0) / max_steps)      # train.py:207: progress counts from the resume point
+        if mc.class_dropout_prob > 0:                          # train.py:208 (no draw at probability 0)
+            M.class_dropout_(y, mc.class_dropout_prob)
         for a in range(accum):
             xs, ys = x[a * mb:(a + 1) * mb], y[a * mb:(a + 1) * mb].contiguous()
             sync = a == accum - 1
             if world > 1 and not sync:
                 with model.no_sync():
-                    (loss_fn(model, xs, ys, mask_ratio=ratio, mae_loss_coef=mc.mae_loss_coef).mean() / accum).backward()
-                continue
-            loss = loss_fn(model, xs, ys, mask_ratio=ratio, mae_loss_coef=mc.mae_loss_coef)
-            (loss.mean() / accum).backward()
-            running += loss.detach().mean()
+                    loss = loss_fn(model, xs, ys, mask_ratio=ratio, mae_loss_coef=mc.mae_loss_coef)
+                    (loss.mean() / accum).backward()
+            else:
+                loss = loss_fn(model, xs, ys, mask_ratio=ratio, mae_loss_coef=mc.mae_loss_coef)
+                (loss.mean() / accum).backward()
+            running += loss.detach().mean() / accum            # train.py:226,232: every accumulation round counts
         if world > 1:
             model.finish_grad_sync()
         for g in opt.param_groups:                             # train.py:223-225
             g['lr'] = tc.lr * lr_rampup_factor(step, global_batch, tc.get('lr_rampup_kimg', 0))
         opt.step()
-        M.update_ema(ema, net)                                 # folded into opt.step()
+        M.update_ema(ema, net)                                 # train.py:230 (folded into opt.step())
         step += 1
         log_steps += 1
         if step % cfg.log.log_every == 0:
@@ -118,16 +159,27 @@ def main():
             if world > 1:
                 dist.all_reduce(avg, op=dist.ReduceOp.SUM)
                 avg = avg / world
+            last_loss = avg.item()
             if rank == 0:
-                print(f'(step={step:07d}) Train Loss: {avg.item():.4f}, Train Steps/Sec: {sps:.2f}, '
+                print(f'(step={step:07d}) Train Loss: {last_loss:.4f}, Train Steps/Sec: {sps:.2f}, '
                       f'img/s: {sps * global_batch:.1f}, mem: {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB', flush=True)
             running.zero_()
             log_steps, t0 = 0, time.time()
-        if step % cfg.log.ckpt_every == 0 and rank == 0:
+        if step % cfg.log.ckpt_every == 0 and step > step0 and rank == 0:  # train.py:259-271
             torch.save({'model': net.state_dict(), 'ema': ema.state_dict(), 'opt': opt.state_dict(), 'args': vars(args)},
                        os.path.join(exp_dir, 'checkpoints', f'{step:07d}.pt'))
+        if step >= step0 + max_steps:                          # train.py:236: max_num_steps MORE steps
+            break
+    if hasattr(batches, 'close'):
+        batches.close()
     if world > 1:
         dist.barrier()
+    return {'net': net, 'ema': ema, 'opt': opt, 'step': step, 'loss': last_loss, 'exp_dir': exp_dir}
+
+
+def main():
+    train_loop(parse())
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
