@@ -26,7 +26,7 @@ Extra objects in the line:
   cpu_baseline : the CPU oracle (oracle/maskdit_oracle.py, a restatement of the reference
                  path pinned to reference-generated fixtures) timed on this host's cores on a
                  bounded sample (XL/2, batch 16, fwd+bwd+AdamW+EMA: >= 3 warm-up + 3 timed steps; thread count
-                 chosen among 32/64/128/all by the warm-up steps and stated) + the 50-step sampler (batch 4,
+                 chosen among 32/16/64 by the warm-up steps and stated; more threads are slower on the GPU box) + the 50-step sampler (batch 4,
                  6 steps timed and scaled by 99/11 network evaluations), rank 0, N = 1 only.
 
 `python bench.py --gpus N` WITHOUT torch.distributed.run re-executes itself under it (one rank per GPU).
@@ -200,12 +200,12 @@ def cpu_baseline(batch, model, R, budget_s=240.0):
     """Bounded CPU leg (BASELINE.md section 3): the oracle's training step (fwd + bwd + AdamW + EMA;
     oracle/maskdit_oracle.py) in a child process with a wall-clock budget, so that a slow / oversubscribed host can
     never stall the benchmark: 1 cold step, >= 3 warm-up steps that also pick the thread count (a 16-sample fp32
-    batch does not scale to all 256 hardware threads of the GPU box: the candidates 32 / 64 / 128 / all are each
-    timed once and the fastest is used and reported), 3 timed steps, then 6 sampler steps."""
+    batch does not scale to the 256 hardware threads of the GPU box -- measured there: 32 threads 7.1 s/step, 64 threads
+    11.1 s, 128 threads 22.7 s -- so the candidates 32 / 16 / 64 are each timed once and the fastest is used and reported), 3 timed steps, then 6 sampler steps."""
     import subprocess
     import tempfile
     cores = os.cpu_count() or 1
-    cands = sorted({min(cores, c) for c in (32, 64, 128, cores)})
+    cands = sorted({min(cores, c) for c in (32, 16, 64)}, key=lambda c: (c != min(cores, 32), c))  # 32 first (cold step)
     out = tempfile.NamedTemporaryFile(prefix='mdt_cpu_', suffix='.json', delete=False).name
     env = dict(os.environ, HIP_VISIBLE_DEVICES='')
     env.pop('OMP_NUM_THREADS', None)

@@ -5,7 +5,9 @@ hipGraph-captured EDM Heun sampler with classifier-free guidance, latents writte
 
     python generate.py --config configs/xl2-256-synthetic.yaml --seeds 0-63 --num_steps 50 --cfg_scale 1.5 \
         [--ckpt_path 2000000.pt] [--outdir samples]
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 generate.py ...   # seeds sharded by rank
 
+Seeds are split over the ranks exactly as sample.py:233-235 does (no exchange step: replicas only).
 The VAE decode + PNG step of the reference (sample.py:273-296) is out of scope (weights are not
 available offline): the fp64 latents `z` are the product."""
 from __future__ import annotations
@@ -21,24 +23,6 @@ import maskdit_amd as M
 from maskdit_amd.schedule import load_config
 
 
-class StackedRandomGenerator:
-    """utils.py:119-133: one torch.Generator per sample seed, draws stacked along the batch."""
-
-    def __init__(self, device, seeds):
-        self.generators = [torch.Generator(device).manual_seed(int(s) % (1 << 32)) for s in seeds]
-
-    def randn(self, size, **kw):
-        assert size[0] == len(self.generators)
-        return torch.stack([torch.randn(size[1:], generator=g, **kw) for g in self.generators])
-
-    def randn_like(self, x):
-        return self.randn(x.shape, dtype=x.dtype, layout=x.layout, device=x.device)
-
-    def randint(self, *a, size, **kw):
-        assert size[0] == len(self.generators)
-        return torch.stack([torch.randint(*a, size=size[1:], generator=g, **kw) for g in self.generators])
-
-
 def parse_seeds(s):
     out = []
     for part in s.split(','):
@@ -50,7 +34,15 @@ def parse_seeds(s):
     return out
 
 
-def main():
+def load_weights(net, path, key='ema'):
+    """generate.py:44-49: the `ema` weights of a training checkpoint; keys written from a torch.compile'd module carry
+    an `_orig_mod.` prefix."""
+    ck = torch.load(path, map_location='cpu', weights_only=False)
+    sd = ck[key] if key in ck else ck
+    net.load_state_dict({k.replace('_orig_mod.', ''): v for k, v in sd.items()})
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--config', required=True)
     ap.add_argument('--ckpt_path', default=None)
@@ -60,20 +52,26 @@ def main():
     ap.add_argument('--num_steps', type=int, default=50)
     ap.add_argument('--cfg_scale', type=float, default=None)
     ap.add_argument('--class_idx', type=int, default=None)
-    args = ap.parse_args()
+    ap.add_argument('--subdirs', action='store_true', help='one sub-directory per 1000 seeds (sample.py:288)')
+    args = ap.parse_args(argv)
     cfg = load_config(args.config)
-    dev = torch.device('cuda', 0)
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
     mc = cfg.model
     net = M.Precond_models[mc.precond](img_resolution=mc.in_size, img_channels=mc.in_channels, num_classes=mc.num_classes,
                                        model_type=mc.model_type, use_decoder=mc.use_decoder, mae_loss_coef=mc.mae_loss_coef,
                                        pad_cls_token=mc.pad_cls_token).to(dev).eval()
     if args.ckpt_path:
-        net.load_state_dict(torch.load(args.ckpt_path, map_location='cpu')['ema'])
+        load_weights(net, args.ckpt_path)
     os.makedirs(args.outdir, exist_ok=True)
     t0, n = time.time(), 0
-    for i in range(0, len(args.seeds), args.max_batch_size):
-        seeds = args.seeds[i:i + args.max_batch_size]
-        rnd = StackedRandomGenerator(dev, seeds)
+    for seeds in M.seed_batches(args.seeds, args.max_batch_size, rank, world):
+        if not seeds:
+            continue
+        rnd = M.StackedRandomGenerator(dev, seeds)
         latents = rnd.randn([len(seeds), net.img_channels, net.img_resolution, net.img_resolution], device=dev)
         labels = torch.eye(net.num_classes, device=dev)[rnd.randint(net.num_classes, size=[len(seeds)], device=dev)]
         if args.class_idx is not None:
@@ -81,10 +79,13 @@ def main():
             labels[:, args.class_idx] = 1
         z = M.edm_sampler(net, latents, labels, cfg_scale=args.cfg_scale, randn_like=rnd.randn_like, num_steps=args.num_steps)
         for s, zi in zip(seeds, z.cpu().numpy()):
-            np.save(os.path.join(args.outdir, f'{s:06d}.npy'), zi)
+            d = os.path.join(args.outdir, f'{s - s % 1000:06d}') if args.subdirs else args.outdir
+            os.makedirs(d, exist_ok=True)
+            np.save(os.path.join(d, f'{s:06d}.npy'), zi)
         n += len(seeds)
     torch.cuda.synchronize()
-    print(f'{n} latents, {args.num_steps} steps, cfg={args.cfg_scale}: {n / (time.time() - t0):.2f} samples/s')
+    print(f'[rank {rank}/{world}] {n} latents, {args.num_steps} steps, cfg={args.cfg_scale}: {n / (time.time() - t0):.2f} samples/s', flush=True)
+    return n
 
 
 if __name__ == '__main__':

@@ -10,6 +10,8 @@ reference's Python surface:
     edm_sampler                                                  <- sample.py
     DataParallel                                                 <- accelerate / DDP (train.py:178)
     sample, class_dropout_                                       <- utils.py:59-65, train.py:208-209
+    StackedRandomGenerator, seed_batches                         <- utils.py:119-133, sample.py:233-235
+    data.{WdsTarLatents, LmdbLatents, LatentPrefetcher}          <- train_wds.py:58-97, train_utils/datasets.py:240-304
 
 There is no non-HIP fallback: computing without libmaskdit_hip.so or off-GPU raises.
 """
@@ -21,4 +23,4 @@ from .loss import EDMLoss, Losses, unwrap_model  # noqa: F401
 from .optim import FusedAdam, update_ema  # noqa: F401
 from .sampler import edm_sampler  # noqa: F401
 from .ddp import DataParallel, GradSlabReducer  # noqa: F401
-from .latents import class_dropout_, sample  # noqa: F401
+from .latents import StackedRandomGenerator, class_dropout_, sample, seed_batches  # noqa: F401

@@ -301,14 +301,23 @@ class Engine:
 
     # ---- plans -------------------------------------------------------------------------
     def plan(self, B: int, masked: bool, train: bool, L: Optional[int] = None) -> 'PassPlan':
-        L = (L if L is not None else self.sp.T // 2) if masked else None
-        key = (B, masked, train, L)
+        """Plans are keyed on the kept-token count ROUNDED UP to the 64-row tile: a mask-ratio schedule
+        (train_utils/helper.py:9-27) changes the exact count nearly every step, but buffers and launch lists only
+        depend on the padded count -- the exact one is a run-time argument of the four launches that read it
+        (PassPlan.set_valid)."""
+        Lv = (L if L is not None else self.sp.T // 2) if masked else None
+        key = (B, masked, train, _rup(Lv, 64) if masked else None)
         pl = self._plans.get(key)
         if pl is None:
+            if train:  # one training plan holds ~0.2 GB of activations per sample: never two shapes at once
+                for k in [k for k in self._plans if k[2]]:
+                    self._plans.pop(k)
             if len(self._plans) >= 4:  # buffers are large: keep few shapes alive
                 self._plans.pop(next(iter(self._plans)))
-            pl = PassPlan(self, B, masked, train, L)
+            pl = PassPlan(self, B, masked, train, Lv)
             self._plans[key] = pl
+        elif masked:
+            pl.set_valid(Lv)
         return pl
 
     def release_plans(self):
@@ -352,12 +361,23 @@ class PassPlan:
         if not (1 <= self.Lv <= sp.T):
             raise ValueError(f'kept-token count {self.Lv} outside [1, {sp.T}]')
         self.L = _rup(self.Lv, 64)
+        # the exact count as a MUTABLE C int inside the pre-marshalled argument tuples (ctypes reads .value at call
+        # time): attention key masking + the un-masking gather / scatter are the only launches that see it
+        self.lv_arg = C.c_int(self.Lv)
+        self.lv_attn = C.c_int(self.Lv if masked else 0)
         self.Bp = _rup(B, 64)
         self.buf: Dict[str, torch.Tensor] = {}
         self.fwd = Plan()
         self.bwd = Plan()
         self.gen = 0  # forward generation: the saved activations belong to the LAST forward through this plan
         self._build()
+
+    def set_valid(self, Lv: int):
+        if _rup(Lv, 64) != self.L or not (1 <= Lv <= self.T):
+            raise ValueError(f'kept-token count {Lv} does not belong to this plan (padded count {self.L})')
+        self.Lv = Lv
+        self.lv_arg.value = Lv
+        self.lv_attn.value = Lv
 
     # ---- buffers -----------------------------------------------------------------------
     def t(self, name, shape, dtype):
@@ -427,7 +447,7 @@ class PassPlan:
         xs_e = [x0]
         for i in range(sp.depth):
             xs_e.append(self._block_fwd(f'model.blocks.{i}', 'e', i, xs_e[-1], mod, sp.mod_off('enc', i), D, sp.heads, L, Me,
-                                        lvalid=self.Lv))
+                                        lvalid=self.lv_attn))
         # ---------------- decoder layer + unmask ----------------------------------------------
         self.marks = {'enc_fwd_end': len(f.calls)}  # launch index where the encoder (+ conditioning path) forward ends
         odl = sp.mod_off('dl')
@@ -442,7 +462,7 @@ class PassPlan:
         xd0 = self.f32('x_d0', Md, Dd)
         use_mt = self.masked and sp.mae
         f.add('mdt_unmask_fwd', xdec.data_ptr(), (ids32.data_ptr() + 4 * T) if self.masked else None, 2 * T,
-              Pf('model.mask_token') if use_mt else None, eng.dpos.data_ptr(), xd0.data_ptr(), B, T, self.Lv, Dd, L)
+              Pf('model.mask_token') if use_mt else None, eng.dpos.data_ptr(), xd0.data_ptr(), B, T, self.lv_arg, Dd, L)
         xs_d = [xd0]
         for i in range(sp.ddepth):
             xs_d.append(self._block_fwd(f'model.decoder_blocks.{i}', 'd', i, xs_d[-1], mod, sp.mod_off('dec', i), Dd, sp.dheads, T, Md))
@@ -483,7 +503,7 @@ class PassPlan:
             self._slab(f'dec{i}')
         dxdec = self.b16('dxdec', Me, Dd)
         g.add('mdt_unmask_bwd', dxd.data_ptr(), ids32.data_ptr() if self.masked else None, 2 * T, dxdec.data_ptr(),
-              Gf('model.mask_token') if use_mt else None, B, T, self.Lv, Dd, L)
+              Gf('model.mask_token') if use_mt else None, B, T, self.lv_arg, Dd, L)
         g.add('mdt_gemm_tn', C.byref(self._k(_tn(dxdec.data_ptr(), Dd, xnd.data_ptr(), D, Me, Dd, D,
                                                Gf('model.decoder_layer.linear.weight'), D))))
         g.add('mdt_colsum_bf16', dxdec.data_ptr(), Dd, Gf('model.decoder_layer.linear.bias'), Me, Dd)
@@ -514,7 +534,7 @@ class PassPlan:
             nxt = self._gate_info(f'model.blocks.{i - 1}', 'e', i - 1, mod, dmod, sp.mod_off('enc', i - 1), D, Gf) \
                 if (i > 0 and FUSE_LN_GATE) else None
             self._block_bwd(f'model.blocks.{i}', 'e', i, xs_e[i], mod, dmod, sp.mod_off('enc', i), D, sp.heads, L, Me, dxe, Gf,
-                            fuse_next=nxt, skip_first_gate=FUSE_LN_GATE, lvalid=self.Lv)
+                            fuse_next=nxt, skip_first_gate=FUSE_LN_GATE, lvalid=self.lv_attn)
             self._slab(f'enc{i}')
             if f'ada_w_enc{i}' in groups:  # block i is the lowest block of its group
                 ada_group(f'ada_w_enc{i}', *groups[f'ada_w_enc{i}'])

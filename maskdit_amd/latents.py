@@ -1,6 +1,7 @@
 """Host mirror of the two small per-batch transforms in front of the loss (train.py:203,208-209):
-`utils.sample` (moments -> scaled latent) and label dropout.  The random numbers are drawn with
-torch in the reference's order; the arithmetic runs in HIP."""
+`utils.sample` (moments -> scaled latent) and label dropout -- the random numbers are drawn with
+torch in the reference's order, the arithmetic runs in HIP -- and of the per-seed random source of the
+sampling entry point (`utils.StackedRandomGenerator`, utils.py:119-133; sample.py:260-264)."""
 from __future__ import annotations
 
 import torch
@@ -34,3 +35,42 @@ def class_dropout_(y: torch.Tensor, class_dropout_prob: float) -> torch.Tensor:
     u = torch.rand(y.shape[0], 1, device=y.device)
     call('mdt_class_dropout', y.data_ptr(), u.data_ptr(), float(class_dropout_prob), y.shape[0], y.shape[1], _st())
     return y
+
+
+class StackedRandomGenerator:
+    """Per-sample-seed random source (utils.py:119-133): sample k of a batch draws from its OWN torch.Generator seeded
+    with seeds[k] mod 2^32, so an image depends on its seed only, not on the batch it was generated in.  Same call
+    surface as the reference (`randn(size, **kw)`, `randn_like(x)`, `randint(*args, size=..., **kw)`); pinned against
+    reference-generated draws by tests/test_host_cpu.py::test_stacked_random_generator_matches_reference."""
+
+    def __init__(self, device, seeds):
+        self.device = torch.device(device)
+        self.seeds = [int(s) & 0xFFFFFFFF for s in seeds]
+        self.generators = []
+        for s in self.seeds:
+            g = torch.Generator(self.device)
+            g.manual_seed(s)
+            self.generators.append(g)
+
+    def _per_sample(self, draw, size):
+        if size[0] != len(self.generators):
+            raise AssertionError(f'leading dimension {size[0]} != number of seeds {len(self.generators)}')
+        tail = tuple(size[1:])
+        return torch.stack([draw(tail, g) for g in self.generators], dim=0)
+
+    def randn(self, size, **kwargs):
+        return self._per_sample(lambda shp, g: torch.randn(shp, generator=g, **kwargs), size)
+
+    def randn_like(self, input):
+        return self.randn(input.shape, dtype=input.dtype, layout=input.layout, device=input.device)
+
+    def randint(self, *args, size, **kwargs):
+        return self._per_sample(lambda shp, g: torch.randint(*args, size=shp, generator=g, **kwargs), size)
+
+
+def seed_batches(seeds, max_batch_size: int, rank: int = 0, world: int = 1):
+    """sample.py:233-235: the seed list is split into `num_batches` (a multiple of the world size, each at most
+    max_batch_size long) contiguous chunks; rank r takes chunks r, r + world, ...  No exchange between ranks."""
+    seeds = torch.as_tensor(list(seeds))
+    num_batches = ((len(seeds) - 1) // (max_batch_size * world) + 1) * world
+    return [b.tolist() for b in seeds.tensor_split(num_batches)[rank::world]]

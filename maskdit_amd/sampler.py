@@ -7,14 +7,14 @@ evaluation, the EDM output blend, Euler update, second evaluation, Heun average,
 bump -- is captured ONCE into a hipGraph on a side stream; every step replays that graph,
 reading its scalars (t_i, t_{i+1}) from a device-side fp64 schedule indexed by a device-side
 counter.  The last step (no 2nd-order correction, sample.py:61) replays a second, shorter graph.
-With S_churn > 0 the generic loop below runs (network still in HIP, state algebra in torch).
+`use_graph=False` issues the SAME launch sequence directly on the stream (no capture): same kernels, same bits.
+Stochastic churn (S_churn > 0; sample.py:51-53) is outside every shipped configuration and raises.
 """
 from __future__ import annotations
 
 import ctypes as C
 from typing import Dict, Tuple
 
-import numpy as np
 import torch
 
 from . import _lib
@@ -141,16 +141,19 @@ def edm_sampler(net, latents, class_labels=None, cfg_scale=None, feat=None, rand
     B = latents.shape[0]
     labels = raw._labels(class_labels, B, latents.device)
     x_next = latents.to(torch.float64) * t_steps[0]  # sample.py:46
-    if S_churn != 0 or not use_graph:
-        return _generic_loop(raw, x_next, t_steps, labels, cfg_scale, randn_like, num_steps, S_churn, S_min, S_max, S_noise)
+    if S_churn != 0:
+        raise NotImplementedError('edm_sampler: S_churn > 0 (stochastic sampling) is outside the shipped configurations '
+                                  '(configs/test/*.yaml, generate.py defaults: S_churn = 0)')
 
     use_cfg = cfg_scale is not None
     g = _graphed(raw, B, use_cfg)
     if num_steps + 1 > g.t_steps.numel():
         raise ValueError('num_steps exceeds the captured schedule capacity (1024)')
     s = float(cfg_scale) if use_cfg else 0.0
-    if g.graph_full is None or g.captured_cfg != s or raw.engine().shadows_dirty:
+    if use_graph and (g.graph_full is None or g.captured_cfg != s or raw.engine().shadows_dirty):
         g.capture(s)
+    if not use_graph and raw.engine().shadows_dirty:
+        raw.engine().refresh_shadows()
     L = _lib.lib()
     cur = torch.cuda.current_stream()
     g.t_steps[:num_steps + 1].copy_(t_steps)
@@ -168,28 +171,12 @@ def edm_sampler(net, latents, class_labels=None, cfg_scale=None, feat=None, rand
             # keep the caller's generator in the same state as the reference would leave it
             randn_like(g.x_hat.view_as(latents))
             last = i == num_steps - 1
-            _lib.check(L.mdt_graph_launch(g.graph_last if last else g.graph_full, st), 'mdt_graph_launch')
+            if use_graph:
+                _lib.check(L.mdt_graph_launch(g.graph_last if last else g.graph_full, st), 'mdt_graph_launch')
+            else:
+                g._record(st, s, last)
             if not last:
                 g.x_hat.copy_(g.x_next)  # x_cur <- x_next (sample.py:48); on the same stream, after the graph
         out = g.x_next.clone().view_as(x_next)
     cur.wait_stream(g.stream)
     return out
-
-
-def _generic_loop(net, x_next, t_steps, labels, cfg_scale, randn_like, num_steps, S_churn, S_min, S_max, S_noise):
-    """sample.py:47-64 verbatim in structure (stochastic churn supported); used when the
-    graph path does not apply."""
-    for i in range(num_steps):
-        t_cur, t_next = t_steps[i], t_steps[i + 1]
-        x_cur = x_next
-        gamma = min(S_churn / num_steps, np.sqrt(2) - 1) if S_min <= t_cur <= S_max else 0
-        t_hat = net.round_sigma(t_cur + gamma * t_cur)
-        x_hat = x_cur + (t_hat ** 2 - t_cur ** 2).sqrt() * S_noise * randn_like(x_cur)
-        denoised = net(x_hat.float(), t_hat, labels, cfg_scale)['x'].to(torch.float64)
-        d_cur = (x_hat - denoised) / t_hat
-        x_next = x_hat + (t_next - t_hat) * d_cur
-        if i < num_steps - 1:
-            denoised = net(x_next.float(), t_next, labels, cfg_scale)['x'].to(torch.float64)
-            d_prime = (x_next - denoised) / t_next
-            x_next = x_hat + (t_next - t_hat) * (0.5 * d_cur + 0.5 * d_prime)
-    return x_next

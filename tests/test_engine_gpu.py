@@ -207,7 +207,7 @@ def test_xl2_sampler_50_steps_vs_reference_fixture(golden_dir):
     rms = ((z.cpu() - ref).norm() / ref.norm()).item()
     print(f'XL/2 50-step sampler (bf16 net) vs reference (fp32 net): rel-to-max err {e:.3e}, rel L2 err {rms:.3e}')
     assert z.dtype == torch.float64 and bool(torch.isfinite(z).all())
-    assert e <= 2e-2 and rms <= 1e-2
+    assert e <= 3e-3 and rms <= 3e-3  # measured 7.1e-4 / 8.0e-4 on MI355X (99 bf16 network evaluations)
 
 
 def test_generic_net_autograd_path_matches_fused_loss(golden_dir):
@@ -273,7 +273,7 @@ def test_sampler_vs_reference_fixture(golden_dir):
     assert z.dtype == torch.float64 and z.shape == lat.shape
     e = _relmax(z, torch.from_numpy(g['z']))
     print(f'sampler (cfg, graph) rel-to-max err {e:.3e}')
-    assert e <= 5e-3  # 11 bf16 network evaluations compound (measured 1.6e-3)
+    assert e <= 4e-3  # 11 bf16 network evaluations compound (measured 1.1e-3)
     z_again = M.edm_sampler(net, lat, labels, cfg_scale=float(g['cfg_scale']), num_steps=n)  # graph replay
     assert torch.equal(z, z_again)
     z_generic = M.edm_sampler(net, lat, labels, cfg_scale=float(g['cfg_scale']), num_steps=n, use_graph=False)
@@ -283,7 +283,7 @@ def test_sampler_vs_reference_fixture(golden_dir):
     z2 = M.edm_sampler(net, lat, labels, cfg_scale=None, num_steps=n)
     e2 = _relmax(z2, torch.from_numpy(g['z_nocfg']))
     print(f'sampler (no cfg) rel-to-max err {e2:.3e}')
-    assert e2 <= 5e-3
+    assert e2 <= 4e-3
 
 
 def test_state_dict_roundtrip_and_rebinding():

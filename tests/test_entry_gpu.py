@@ -1,0 +1,132 @@
+"""The training / sampling entry points end to end on the GPU (S/2, tiny batches): train.py's loop, checkpoint dict,
+resume semantics (the EMA must NOT be re-initialised from the model on resume, progress and the stop
+condition count from the resume point), non-strict finetune load, `_orig_mod.` key prefix, train_wds.py fed from
+reference-layout tar shards through the prefetcher, generate.py's per-seed latents."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CFG = """
+model: {precond: edm, model_type: DiT-S/2, in_size: 32, in_channels: 4, num_classes: 1000, use_decoder: true,
+        pad_cls_token: false, ext_feature_dim: 0, mask_ratio: 0.5, mask_ratio_fn: %s, mask_ratio_min: 0.25,
+        mae_loss_coef: 0.1, class_dropout_prob: 0.1}
+train: {batchsize: 16, grad_accum: 2, lr: 1.0e-3, lr_rampup_kimg: 0, max_num_steps: 6}
+data: {category: %s, resolution: 32, num_channels: 4, root: %s}
+log: {log_every: 2, ckpt_every: 3}
+"""
+
+
+def _cfg(tmp_path, fn='constant', cat='synthetic', root='none'):
+    p = os.path.join(tmp_path, f'cfg_{fn}_{cat}.yaml')
+    with open(p, 'w') as f:
+        f.write(CFG % (fn, cat, root))
+    return p
+
+
+def test_train_loop_checkpoint_and_resume(tmp_path):
+    import train as T
+    import maskdit_amd as M
+    tmp = str(tmp_path)
+    cfg = _cfg(tmp)
+    out = T.train_loop(T.parse(['--config', cfg, '--results_dir', tmp, '--exp_name', 'a', '--max_num_steps', '6']))
+    assert out['step'] == 6 and out['loss'] is not None and np.isfinite(out['loss'])
+    ck_dir = os.path.join(tmp, 'a', 'checkpoints')
+    assert sorted(os.listdir(ck_dir)) == ['0000003.pt', '0000006.pt']  # train.py:259-271 naming
+    ck = torch.load(os.path.join(ck_dir, '0000003.pt'), map_location='cpu', weights_only=False)
+    assert set(ck) == {'model', 'ema', 'opt', 'args'} and ck['opt']['param_groups'][0]['step'] == 3
+    # after 3 steps with decay 0.9999 the EMA is close to, but not equal to, the model
+    k = 'model.blocks.0.attn.qkv.weight'
+    assert not torch.equal(ck['model'][k], ck['ema'][k])
+    # ---- resume from step 3 for 2 more steps: counter, stop condition, EMA preserved
+    out2 = T.train_loop(T.parse(['--config', cfg, '--results_dir', tmp, '--exp_name', 'b', '--max_num_steps', '2',
+                                 '--ckpt_path', os.path.join(ck_dir, '0000003.pt')]))
+    assert out2['step'] == 5  # 3 + max_num_steps MORE steps (train.py:236), not "until step 2"
+    ema_after = dict(out2['ema'].named_parameters())[k].detach().cpu()
+    net_after = dict(out2['net'].named_parameters())[k].detach().cpu()
+    # EMA after 2 resumed steps = 0.9999^2 * loaded EMA + ...: it must still be within 1e-3 of the LOADED EMA and
+    # must not have been overwritten by the model (which has moved by ~lr per step since the fresh start)
+    assert (ema_after - ck['ema'][k]).abs().max() < (ema_after - net_after).abs().max()
+    assert not torch.equal(ema_after, net_after)
+    assert out2['opt'].param_groups[0]['step'] == 5
+    # ---- a non-constant schedule changes the kept-token count from step to step without leaking plans / memory
+    cfg2 = _cfg(tmp, fn='linear')
+    out3 = T.train_loop(T.parse(['--config', cfg2, '--results_dir', tmp, '--exp_name', 'c', '--max_num_steps', '4']))
+    assert out3['step'] == 4 and np.isfinite(out3['loss'])
+
+
+def test_finetune_load_is_non_strict_and_tolerates_compile_prefix(tmp_path):
+    """train.py:149-157 with --use_strict_load False: model / ema load with strict=False (missing and unexpected keys
+    allowed), the optimizer state is NOT loaded; generate.py:46-48 strips `_orig_mod.`."""
+    import train as T
+    import generate as G
+    import maskdit_amd as M
+    tmp = str(tmp_path)
+    cfg = _cfg(tmp)
+    out = T.train_loop(T.parse(['--config', cfg, '--results_dir', tmp, '--exp_name', 'a', '--max_num_steps', '3']))
+    path = os.path.join(tmp, 'a', 'checkpoints', '0000003.pt')
+    ck = torch.load(path, map_location='cpu', weights_only=False)
+    pruned = {k: v for k, v in ck['model'].items() if 'mask_token' not in k}
+    pruned['model.some_new_head.weight'] = torch.zeros(3)
+    ft = os.path.join(tmp, 'finetune_src.pt')
+    torch.save({'model': {'_orig_mod.' + k: v for k, v in pruned.items()}, 'ema': ck['ema'], 'opt': ck['opt']}, ft)
+    with pytest.raises(RuntimeError):  # strict (the default) refuses the pruned dict
+        T.train_loop(T.parse(['--config', cfg, '--results_dir', tmp, '--exp_name', 'x', '--max_num_steps', '1', '--ckpt_path', ft]))
+    out2 = T.train_loop(T.parse(['--config', cfg, '--results_dir', tmp, '--exp_name', 'y', '--max_num_steps', '1', '--ckpt_path', ft,
+                                 '--use_strict_load', 'False']))
+    assert out2['opt'].param_groups[0]['step'] == 1  # fresh optimizer state (train.py:152: only under strict load)
+    # generate.py's loader: ema weights, compile prefix stripped
+    net = M.Precond_models['edm'](img_resolution=32, img_channels=4, num_classes=1000, model_type='DiT-S/2').to('cuda').eval()
+    torch.save({'ema': {'_orig_mod.' + k: v for k, v in ck['ema'].items()}}, os.path.join(tmp, 'e.pt'))
+    G.load_weights(net, os.path.join(tmp, 'e.pt'))
+    assert torch.equal(net.state_dict()['model.blocks.3.mlp.fc1.weight'].cpu(), ck['ema']['model.blocks.3.mlp.fc1.weight'])
+
+
+def test_train_wds_from_reference_layout_shards(tmp_path):
+    """BASELINE configs[3] entry point on S/2-sized data: tar shards in the reference's layout -> WdsTarLatents ->
+    pinned-memory prefetcher -> sample() / one-hot / dropout on the device -> training steps."""
+    import train_wds as TW
+    import train as T
+    from maskdit_amd import data as D
+    tmp = str(tmp_path)
+    shard_dir = os.path.join(tmp, 'shards')
+    os.makedirs(shard_dir)
+    rng = np.random.default_rng(0)
+    for s in range(2):
+        mean = (2.745 * rng.standard_normal((48, 4, 32, 32))).astype(np.float32)
+        D.write_wds_shard(os.path.join(shard_dir, f's{s}.tar'), np.concatenate([mean, np.full_like(mean, -10.0)], 1),
+                          rng.integers(0, 1000, 48), start_index=48 * s)
+    cfg = _cfg(tmp, cat='webdataset', root=shard_dir)
+    args = T.parse(['--config', cfg, '--results_dir', tmp, '--exp_name', 'w', '--max_num_steps', '4'])
+    args.default_category = 'wds'
+    out = T.train_loop(args)
+    assert out['step'] == 4 and np.isfinite(out['loss']) and 0.3 < out['loss'] < 5.0
+    # prefetcher on the GPU: contents arrive intact and in order
+    pf = D.LatentPrefetcher(D.WdsTarLatents(shard_dir, batch=32, shuffle_buf=0), 'cuda', depth=2)
+    got = [(m.clone(), l.clone()) for m, l in pf]
+    ref = list(D.WdsTarLatents(shard_dir, batch=32, shuffle_buf=0))
+    assert len(got) == len(ref) == 3
+    for (m, l), (rm, rl) in zip(got, ref):
+        assert m.is_cuda and torch.equal(m.cpu(), torch.from_numpy(rm)) and torch.equal(l.cpu(), torch.from_numpy(rl))
+
+
+def test_generate_writes_per_seed_latents(tmp_path):
+    import generate as G
+    tmp = str(tmp_path)
+    cfg = _cfg(tmp)
+    n = G.main(['--config', cfg, '--seeds', '5-9', '--num_steps', '4', '--cfg_scale', '1.5', '--outdir', os.path.join(tmp, 's'),
+                '--max_batch_size', '3'])
+    assert n == 5 and sorted(os.listdir(os.path.join(tmp, 's'))) == [f'{s:06d}.npy' for s in range(5, 10)]
+    a = np.load(os.path.join(tmp, 's', '000007.npy'))
+    assert a.shape == (4, 32, 32) and a.dtype == np.float64 and np.isfinite(a).all()
+    # a sample depends on its seed only: regenerate seed 7 alone (different batch composition)
+    G.main(['--config', cfg, '--seeds', '7', '--num_steps', '4', '--cfg_scale', '1.5', '--outdir', os.path.join(tmp, 't')])
+    b = np.load(os.path.join(tmp, 't', '000007.npy'))
+    assert np.abs(a - b).max() <= 2e-2 * np.abs(a).max()  # bf16 network: batch-size-dependent GEMM tiling only

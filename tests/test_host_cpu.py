@@ -208,3 +208,61 @@ def test_optimizer_state_of_a_reference_checkpoint_maps_by_position(golden_dir):
             st = opt.state[p]
             assert float(st['exp_avg'].flatten()[0]) == float(index[name]) and st['exp_avg'].shape == p.shape, name
             assert float(st['exp_avg_sq'].flatten()[-1]) == index[name] + 0.5, name
+
+
+@pytest.mark.parametrize('fixture', ['s2_sampler.npz', 'xl2_sampler.npz'])
+def test_stacked_random_generator_matches_reference(golden_dir, fixture):
+    """The per-seed latents / class draws of the sampling entry point: fixtures hold what the reference's own
+    utils.StackedRandomGenerator('cpu', seeds) produced (tests/golden/make_golden.py: gen_sampler)."""
+    import maskdit_amd as M
+    g = np.load(os.path.join(golden_dir, fixture))
+    seeds = [int(s) for s in g['seeds']]
+    rnd = M.StackedRandomGenerator('cpu', seeds)
+    lat = rnd.randn([len(seeds), 4, 32, 32])
+    cls = rnd.randint(1000, size=[len(seeds)])
+    assert np.array_equal(lat.numpy(), g['latents']) and np.array_equal(cls.numpy(), g['cls'])
+    # a sample depends on its seed only, not on its batch-mates
+    solo = M.StackedRandomGenerator('cpu', seeds[-1:])
+    assert torch.equal(solo.randn([1, 4, 32, 32])[0], lat[-1])
+    assert rnd.randn_like(lat).shape == lat.shape
+    with pytest.raises(AssertionError):
+        rnd.randn([len(seeds) + 1, 4])
+
+
+def test_seed_batches_shard_like_the_reference():
+    """sample.py:233-235 restated with its own arithmetic: tensor_split into ceil(n / (max_bs * world)) * world chunks,
+    rank-strided; every seed exactly once, no batch above the maximum."""
+    import maskdit_amd as M
+    for n, mb, world in [(64, 64, 1), (50000, 50, 8), (100, 64, 8), (7, 4, 2), (1, 64, 4)]:
+        seeds = list(range(1000, 1000 + n))
+        got = [M.seed_batches(seeds, mb, r, world) for r in range(world)]
+        num = ((n - 1) // (mb * world) + 1) * world
+        ref = [b.tolist() for b in torch.as_tensor(seeds).tensor_split(num)]
+        for r in range(world):
+            assert got[r] == ref[r::world]
+        flat = sorted(s for rb in got for b in rb for s in b)
+        assert flat == seeds and max(len(b) for rb in got for b in rb) <= mb
+
+
+def test_reference_yaml_configs_parse_and_are_supported():
+    """Every training / test YAML the reference ships parses with maskdit_amd.schedule.load_config and names a
+    supported model / flag set.  Reads /root/reference (build container only; skipped elsewhere)."""
+    import glob
+    from maskdit_amd.engine import make_spec
+    from maskdit_amd.schedule import get_mask_ratio_fn, load_config
+    files = sorted(glob.glob('/root/reference/configs/**/*.yaml', recursive=True))
+    if not files:
+        pytest.skip('/root/reference is not present on this machine')
+    for f in files:
+        cfg = load_config(f)
+        mc = cfg.model
+        sp = make_spec(mc.model_type, mc.in_size, mc.in_channels, mc.num_classes, mc.use_decoder, mc.get('mae_loss_coef', 0.1))
+        assert sp.T in (256, 1024) and not mc.pad_cls_token and mc.get('ext_feature_dim', 0) == 0, f
+        if 'train' in cfg:
+            assert cfg.train.batchsize > 0 and cfg.train.lr > 0 and cfg.log.ckpt_every > 0, f
+            name = mc.get('mask_ratio_fn', 'constant')
+            if name == 'cos4':  # configs/finetune/imagenet256-latent-cos.yaml: not a name helper.py:9-27 accepts either
+                with pytest.raises(ValueError):
+                    get_mask_ratio_fn(name, mc.mask_ratio, mc.get('mask_ratio_min', 0))
+            else:
+                get_mask_ratio_fn(name, mc.mask_ratio, mc.get('mask_ratio_min', 0))(0.5)

@@ -216,8 +216,8 @@ def test_gemm_nt8_pipelined(M, N, K):
                     assert (x is None) == (y is None)
                     if x is None:
                         continue
-                    if idx == 3:  # column sums: fp32 atomics in a different order
-                        close(y, x, 1e-5, f'nt8 {key} colsum (epi {kw["epi"]})')
+                    if idx == 3:  # column sums: fp32 atomics in a different order (+ the bf16 flips below for d-activations)
+                        close(y, x, 3e-4 if kw['epi'] in (ops.EPI_DGELU, ops.EPI_DSILU) else 1e-5, f'nt8 {key} colsum (epi {kw["epi"]})')
                     elif kw['epi'] in (ops.EPI_DGELU, ops.EPI_DSILU):
                         # acc * act'(aux): hipcc contracts the product chain into different FMAs in the two kernels, so
                         # the fp32 value can differ in its last bit and an occasional bf16 rounding flips: at most one

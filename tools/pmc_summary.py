@@ -1,7 +1,9 @@
 """Per-kernel HBM traffic from rocprofv3 --pmc runs (rocpd sqlite): FETCH_SIZE / WRITE_SIZE are in KiB;
 on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes for wide coalesced reads
 (/opt/skills/guides/MI355X_MICROARCH.md, section HBM), so the read side is doubled.
-    python tools/pmc_summary.py fetch.db write.db out.json out.txt"""
+    python tools/pmc_summary.py fetch.db write.db out.json out.txt [model resolution micro_batch "command"]
+The optional trailing arguments are recorded in out.json: bench.py only reports `roofline.traffic` when they match the
+benchmarked workload."""
 import json
 import sqlite3
 import sys
@@ -17,7 +19,7 @@ def per_kernel(db_path, counter):
     return {n: (c, v) for n, c, v in db.execute(q, (counter,))}
 
 
-def main(fetch_db, write_db, out_json, out_txt):
+def main(fetch_db, write_db, out_json, out_txt, model=None, resolution=None, micro_batch=None, command=None):
     f = per_kernel(fetch_db, 'FETCH_SIZE')
     w = per_kernel(write_db, 'WRITE_SIZE')
     rows = []
@@ -36,9 +38,11 @@ def main(fetch_db, write_db, out_json, out_txt):
     tot = sum(c * (rd + wr) for c, rd, wr in nt)
     json.dump({'kernel': 'gemm_nt8_kernel + gemm_nt_kernel (all mdt_gemm_nt launches)', 'launches': n,
                'hbm_bytes_per_launch': round(tot / max(n, 1)),
+               'model': model, 'resolution': int(resolution) if resolution else None,
+               'micro_batch': int(micro_batch) if micro_batch else None, 'command': command,
                'note': 'read side = FETCH_SIZE x 2 (gfx950 correction), write side = WRITE_SIZE (uncalibrated)'}, open(out_json, 'w'), indent=1)
     print('\n'.join(lines[:14]))
 
 
 if __name__ == '__main__':
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:9])

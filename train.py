@@ -54,7 +54,8 @@ def make_batches(cfg, args, dev, rank, world, B):
     """Iterator of (moments [B, 2C, R, R] f32, labels int64 [B]) ON THE DEVICE."""
     mc = cfg.model
     R, C = mc.in_size, mc.in_channels
-    cat = cfg.data.get('category', 'synthetic') if 'data' in cfg else 'synthetic'
+    default = getattr(args, 'default_category', 'synthetic')
+    cat = cfg.data.get('category', default) if 'data' in cfg else default
     root = args.data_path or (cfg.data.get('root') if 'data' in cfg else None)
     if cat == 'synthetic':
         gen = torch.Generator(device=dev).manual_seed(1 + rank)
