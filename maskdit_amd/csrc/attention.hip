@@ -478,6 +478,341 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
 }
 
 // ------------------------------------------------------------------------------------------
+// Short sequences (L = 128 * KF <= 256: the masked 256^2 encoder, L = 128, and the decoder / eval encoder,
+// L = 256): ONE 8-wave workgroup per (sample, head), every operand tile staged in LDS exactly once with all
+// global loads issued before the first use (one memory round trip per workgroup instead of one per 64-row
+// block), exact single-pass softmax (the whole key range of a query is in registers).  Rows are stored at their
+// natural odd-chunk pitch (hd 72 -> 144 B, not the 208 B of the contraction-padded form): the zero columns of the
+// last contraction step are produced in registers, so four tiles fit twice per CU.
+//
+// Backward: dQ, dK and dV in one launch.  Phase A: wave w owns keys 16w.. (dK, dV: loop over query blocks);
+// phase B: wave w owns queries 16w.. (dQ: loop over key blocks) -- the same arithmetic as the two separate
+// kernels above, but Q, K, V, dO, O are read from HBM once instead of twice, delta never leaves LDS, and the
+// two exposed load latencies / launches become one.
+
+template <int HD>
+struct SpCfg {
+  static constexpr int CH = HD / 8;
+  static constexpr int PITCH_CH = CH | 1;          // odd 16-byte-chunk pitch: conflict-free ds_read_b128
+  static constexpr int PITCH = PITCH_CH * 16;
+  static constexpr int KSTEPS = AttnCfg<HD>::KSTEPS;
+  static constexpr int NFRAG = AttnCfg<HD>::NFRAG;
+};
+
+// row fragment with the contraction tail (columns >= HD) zeroed in registers
+template <int HD>
+__device__ __forceinline__ bf16x8 sp_frag_rows(const char* tile, int row, int s, int g) {
+  bf16x8 z;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) z[e] = (bf16)0.f;
+  const int d0 = 32 * s + 8 * g;
+  return (d0 < HD) ? *(const bf16x8*)(tile + row * SpCfg<HD>::PITCH + (4 * s + g) * 16) : z;
+}
+// transposed fragment (see frag_cols); output rows >= HD of the consumer MFMA are garbage and never stored
+template <int HD>
+__device__ __forceinline__ bf16x8 sp_frag_cols(const char* tile, int rbase, int fd, int i16, int g) {
+  const char* q = tile + (rbase + 4 * g + (i16 >> 2)) * SpCfg<HD>::PITCH + (16 * fd + 4 * (i16 & 3)) * 2;
+  return cat4(lds_tr_read(q), lds_tr_read(q + 16 * SpCfg<HD>::PITCH));
+}
+
+// global -> registers -> LDS staging of an [ROWS x HD] tile by 512 threads
+template <int HD, int ROWS> struct SpRegs {
+  static constexpr int N = (ROWS * SpCfg<HD>::CH + 511) / 512;
+  bf16x8 v[N];
+};
+template <int HD, int ROWS>
+__device__ __forceinline__ void sp_load(SpRegs<HD, ROWS>& t, const bf16* g, long ld, int tid) {
+  constexpr int CH = SpCfg<HD>::CH;
+#pragma unroll
+  for (int i = 0; i < SpRegs<HD, ROWS>::N; ++i) {
+    const int idx = tid + 512 * i;
+    if (idx < ROWS * CH) {
+      const int r = idx / CH, c = idx - r * CH;
+      t.v[i] = *(const bf16x8*)(g + (long)r * ld + c * 8);
+    }
+  }
+}
+template <int HD, int ROWS>
+__device__ __forceinline__ void sp_store(const SpRegs<HD, ROWS>& t, char* lds, int tid) {
+  constexpr int CH = SpCfg<HD>::CH;
+#pragma unroll
+  for (int i = 0; i < SpRegs<HD, ROWS>::N; ++i) {
+    const int idx = tid + 512 * i;
+    if (idx < ROWS * CH) {
+      const int r = idx / CH, c = idx - r * CH;
+      *(bf16x8*)(lds + r * SpCfg<HD>::PITCH + c * 16) = t.v[i];
+    }
+  }
+}
+
+__device__ __forceinline__ void sp_block_coords(int B, int H, int& b, int& h) {
+  int blk;
+  attn_block_coords(1, B, H, b, h, blk);
+}
+
+template <int HD, int KF>
+__global__ __launch_bounds__(512) void attn_fwd_sp_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                          float* __restrict__ lse, int H, float scale_log2e, int Lv) {
+  using C = SpCfg<HD>;
+  constexpr int L = 128 * KF;
+  constexpr int TILE = L * C::PITCH;
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE + 64];
+  char* Ks = smem;
+  char* Vs = smem + TILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  int b, h;
+  sp_block_coords(gridDim.y / H, H, b, h);
+  const int D = H * HD;
+  const long ld = 3L * D;
+  const bf16* base = qkv + (long)b * L * ld + h * HD;
+
+  // every global load of the workgroup, then one wait
+  SpRegs<HD, L> kreg, vreg;
+  sp_load<HD, L>(kreg, base + D, ld, tid);
+  sp_load<HD, L>(vreg, base + 2 * D, ld, tid);
+  bf16x8 qf[KF][C::KSTEPS];
+#pragma unroll
+  for (int qi = 0; qi < KF; ++qi) load_frag_global<HD>(qf[qi], base + (long)(wave * 16 * KF + 16 * qi + i16) * ld, g);
+  sp_store<HD, L>(kreg, Ks, tid);
+  sp_store<HD, L>(vreg, Vs, tid);
+  __syncthreads();
+
+#pragma unroll
+  for (int qi = 0; qi < KF; ++qi) {
+    const int q = wave * 16 * KF + 16 * qi + i16;  // this lane's query
+    // S^T fragments: rows = keys 16f + 4g + r, col = query i16; the whole key range stays in registers
+    f32x4 s[L / 16];
+#pragma unroll
+    for (int f = 0; f < L / 16; ++f) {
+      s[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < C::KSTEPS; ++ks) s[f] = mfma16(sp_frag_rows<HD>(Ks, 16 * f + i16, ks, g), qf[qi][ks], s[f]);
+    }
+    float mx = -1e30f;
+#pragma unroll
+    for (int f = 0; f < L / 16; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[f][r] = (16 * f + 4 * g + r < Lv) ? s[f][r] * scale_log2e : -1e30f;  // padding keys: no probability mass
+        mx = fmaxf(mx, s[f][r]);
+      }
+    mx = group_max(mx);
+    float psum = 0.f;
+#pragma unroll
+    for (int f = 0; f < L / 16; ++f)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[f][r] = exp2f(s[f][r] - mx);
+        psum += s[f][r];
+      }
+    const float l_tot = group_sum(psum);
+    // O^T = V^T P^T: contraction over keys in steps of 32
+    f32x4 o[C::NFRAG];
+#pragma unroll
+    for (int f = 0; f < C::NFRAG; ++f) o[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < L / 32; ++ks) {
+      const bf16x8 pf = pack_pair(s[2 * ks], s[2 * ks + 1]);
+#pragma unroll
+      for (int f = 0; f < C::NFRAG; ++f) o[f] = mfma16(sp_frag_cols<HD>(Vs, 32 * ks, f, i16, g), pf, o[f]);
+    }
+    const float inv = 1.f / l_tot;
+    bf16* orow = out + ((long)b * L + q) * D + h * HD;
+#pragma unroll
+    for (int f = 0; f < C::NFRAG; ++f) {
+      const int d = 16 * f + 4 * g;
+      if (d < HD) {
+        bf16x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = f2bf(o[f][r] * inv);
+        *(bf16x4*)(orow + d) = v;
+      }
+    }
+    if (g == 0) lse[((long)b * H + h) * L + q] = mx + log2f(l_tot);
+  }
+}
+
+// OCC = waves per SIMD the register allocation aims at: 4 -> two workgroups per CU (<= 128 VGPRs, a few spills
+// outside the inner loops at hd >= 64), 2 -> one workgroup per CU, no spill ("attn_sp" = 2 selects it: A/B knob)
+template <int HD, int KF, int OCC = 4>
+__global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                          const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                          float* __restrict__ delta, bf16* __restrict__ dqkv, int H,
+                                                          float scale, float scale_log2e, int Lv) {
+  using C = SpCfg<HD>;
+  constexpr int L = 128 * KF;
+  constexpr int TILE = L * C::PITCH;
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE + 2 * L * 4 + 64];
+  char* Qs = smem;
+  char* Ks = smem + TILE;
+  char* Vs = smem + 2 * TILE;
+  char* dOs = smem + 3 * TILE;
+  float* lse_s = (float*)(smem + 4 * TILE);
+  float* del_s = lse_s + L;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  int b, h;
+  sp_block_coords(gridDim.y / H, H, b, h);
+  const long bh = (long)b * H + h;
+  const int D = H * HD;
+  const long ld = 3L * D;
+  const bf16* base = qkv + (long)b * L * ld + h * HD;
+  const bf16* dobase = dout + (long)b * L * D + h * HD;
+  const bf16* obase = out + (long)b * L * D + h * HD;
+
+  // ---- every global load up front: four tiles + this wave's O / dO rows for delta = rowsum(dO * O)
+  {
+    SpRegs<HD, L> r0, r1;
+    sp_load<HD, L>(r0, base, ld, tid);
+    sp_load<HD, L>(r1, base + D, ld, tid);
+    SpRegs<HD, L> r2, r3;
+    sp_load<HD, L>(r2, base + 2 * D, ld, tid);
+    sp_load<HD, L>(r3, dobase, D, tid);
+    if (tid < L) lse_s[tid] = lse[bh * L + tid];
+    // delta: KF rows per lane-group of 16 lanes... one row per (wave, qi, i16); g splits the hd range
+#pragma unroll
+    for (int qi = 0; qi < KF; ++qi) {
+      const int q = wave * 16 * KF + 16 * qi + i16;
+      bf16x8 of[C::KSTEPS], dof[C::KSTEPS];
+      load_frag_global<HD>(of, obase + (long)q * D, g);
+      load_frag_global<HD>(dof, dobase + (long)q * D, g);
+      float dl = 0.f;
+#pragma unroll
+      for (int s = 0; s < C::KSTEPS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl += bf2f(dof[s][e]) * bf2f(of[s][e]);
+      dl = group_sum(dl);
+      if (g == 0) {
+        del_s[q] = dl;
+        delta[bh * L + q] = dl;
+      }
+    }
+    sp_store<HD, L>(r0, Qs, tid);
+    sp_store<HD, L>(r1, Ks, tid);
+    sp_store<HD, L>(r2, Vs, tid);
+    sp_store<HD, L>(r3, dOs, tid);
+  }
+  __syncthreads();
+
+  // ---- phase A: this wave's keys -> dK, dV (S fragments: rows = queries 16f + 4g + r, col = key i16)
+#pragma unroll 1
+  for (int ki = 0; ki < KF; ++ki) {
+    const int k0 = wave * 16 * KF + 16 * ki;
+    bf16x8 kf[C::KSTEPS], vf[C::KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < C::KSTEPS; ++ks) {
+      kf[ks] = sp_frag_rows<HD>(Ks, k0 + i16, ks, g);
+      vf[ks] = sp_frag_rows<HD>(Vs, k0 + i16, ks, g);
+    }
+    f32x4 dk[C::NFRAG], dv[C::NFRAG];
+#pragma unroll
+    for (int f = 0; f < C::NFRAG; ++f) {
+      dk[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dv[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool key_ok = (k0 + i16) < Lv;
+#pragma unroll 1
+    for (int qb = 0; qb < L; qb += 64) {
+      f32x4 pm[4], ds[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < C::KSTEPS; ++ks) {
+          s = mfma16(sp_frag_rows<HD>(Qs, qb + 16 * f + i16, ks, g), kf[ks], s);
+          dp = mfma16(sp_frag_rows<HD>(dOs, qb + 16 * f + i16, ks, g), vf[ks], dp);
+        }
+        const f32x4 ls = *(const f32x4*)(lse_s + qb + 16 * f + 4 * g);
+        const f32x4 dl = *(const f32x4*)(del_s + qb + 16 * f + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = key_ok ? exp2f(s[r] * scale_log2e - ls[r]) : 0.f;
+          pm[f][r] = pv;
+          ds[f][r] = pv * (dp[r] - dl[r]) * scale;
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 pf = pack_pair(pm[2 * ks], pm[2 * ks + 1]);
+        const bf16x8 dsf = pack_pair(ds[2 * ks], ds[2 * ks + 1]);
+#pragma unroll
+        for (int f = 0; f < C::NFRAG; ++f) {
+          dv[f] = mfma16(sp_frag_cols<HD>(dOs, qb + 32 * ks, f, i16, g), pf, dv[f]);
+          dk[f] = mfma16(sp_frag_cols<HD>(Qs, qb + 32 * ks, f, i16, g), dsf, dk[f]);
+        }
+      }
+    }
+    bf16* drow = dqkv + ((long)b * L + k0 + i16) * ld + h * HD;
+#pragma unroll
+    for (int f = 0; f < C::NFRAG; ++f) {
+      const int d = 16 * f + 4 * g;
+      if (d < HD) {
+        bf16x4 a, c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          a[r] = f2bf(dk[f][r]);
+          c[r] = f2bf(dv[f][r]);
+        }
+        *(bf16x4*)(drow + D + d) = a;
+        *(bf16x4*)(drow + 2 * D + d) = c;
+      }
+    }
+  }
+
+  // ---- phase B: this wave's queries -> dQ (S^T fragments: rows = keys 16f + 4g + r, col = query i16)
+#pragma unroll 1
+  for (int qi = 0; qi < KF; ++qi) {
+    const int q = wave * 16 * KF + 16 * qi + i16;
+    bf16x8 qf[C::KSTEPS], dof[C::KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < C::KSTEPS; ++ks) {
+      qf[ks] = sp_frag_rows<HD>(Qs, q, ks, g);
+      dof[ks] = sp_frag_rows<HD>(dOs, q, ks, g);
+    }
+    const float my_lse = lse_s[q], dl = del_s[q];
+    f32x4 dq[C::NFRAG];
+#pragma unroll
+    for (int f = 0; f < C::NFRAG; ++f) dq[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kb = 0; kb < L; kb += 64) {
+      f32x4 ds[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < C::KSTEPS; ++ks) {
+          s = mfma16(sp_frag_rows<HD>(Ks, kb + 16 * f + i16, ks, g), qf[ks], s);
+          dp = mfma16(sp_frag_rows<HD>(Vs, kb + 16 * f + i16, ks, g), dof[ks], dp);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = (kb + 16 * f + 4 * g + r < Lv) ? exp2f(s[r] * scale_log2e - my_lse) : 0.f;
+          ds[f][r] = pv * (dp[r] - dl) * scale;
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 dsf = pack_pair(ds[2 * ks], ds[2 * ks + 1]);
+#pragma unroll
+        for (int f = 0; f < C::NFRAG; ++f) dq[f] = mfma16(sp_frag_cols<HD>(Ks, kb + 32 * ks, f, i16, g), dsf, dq[f]);
+      }
+    }
+    bf16* drow = dqkv + ((long)b * L + q) * ld + h * HD;
+#pragma unroll
+    for (int f = 0; f < C::NFRAG; ++f) {
+      const int d = 16 * f + 4 * g;
+      if (d < HD) {
+        bf16x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = f2bf(dq[f][r]);
+        *(bf16x4*)(drow + d) = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 
 #define ATTN_DISPATCH(HD_, CALL) \
   switch (HD_) {                 \
@@ -494,6 +829,18 @@ extern "C" int mdt_attn_fwd(const mdt_bf16* qkv, mdt_bf16* out, float* lse, int 
   MDT_REQUIRE(B > 0 && H > 0 && L > 0 && L % 64 == 0, "attn_fwd: L must be a positive multiple of 64");
   if (L_valid <= 0 || L_valid > L) L_valid = L;
   float sl = (1.0f / sqrtf((float)hd)) * 1.4426950408889634f;
+  // short sequences: one workgroup per (sample, head), single pass ("attn_sp" = 1 forces the block-loop kernels: A/B)
+  if ((L == 128 || L == 256) && mdt_get_tuning_int(MDT_TUNE_ATTN_SP) != 1) {
+    dim3 grid(1, B * H);
+    if (L == 128) {
+      ATTN_DISPATCH(hd, hipLaunchKernelGGL((attn_fwd_sp_kernel<HDc, 1>), grid, dim3(512), 0, (hipStream_t)stream,
+                                           (const bf16*)qkv, (bf16*)out, lse, H, sl, L_valid));
+    } else {
+      ATTN_DISPATCH(hd, hipLaunchKernelGGL((attn_fwd_sp_kernel<HDc, 2>), grid, dim3(512), 0, (hipStream_t)stream,
+                                           (const bf16*)qkv, (bf16*)out, lse, H, sl, L_valid));
+    }
+    return mdt_check_launch("attn_fwd_sp");
+  }
   // two query fragments per wave pay off for the narrow heads (hd <= 64: -8..-10 %); at hd 72/80 the
   // extra registers cost occupancy and the kernel is bound by its 144-byte-segment global reads anyway
   const int qf_knob = mdt_get_tuning_int(MDT_TUNE_ATTN_QF);
@@ -517,6 +864,28 @@ extern "C" int mdt_attn_bwd(const mdt_bf16* qkv, const mdt_bf16* out, const mdt_
   if (L_valid <= 0 || L_valid > L) L_valid = L;
   float sc = 1.0f / sqrtf((float)hd);
   float sl = sc * 1.4426950408889634f;
+  if ((L == 128 || (L == 256 && (hd == 32 || hd == 64 || hd == 72))) && mdt_get_tuning_int(MDT_TUNE_ATTN_SP) != 1) {
+    dim3 g1(1, B * H);
+    if (L == 128 && mdt_get_tuning_int(MDT_TUNE_ATTN_SP) == 2) {
+      ATTN_DISPATCH(hd, hipLaunchKernelGGL((attn_bwd_sp_kernel<HDc, 1, 2>), g1, dim3(512), 0, (hipStream_t)stream,
+                                           (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, H,
+                                           sc, sl, L_valid));
+    } else if (L == 128) {
+      ATTN_DISPATCH(hd, hipLaunchKernelGGL((attn_bwd_sp_kernel<HDc, 1>), g1, dim3(512), 0, (hipStream_t)stream,
+                                           (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, H,
+                                           sc, sl, L_valid));
+    } else {
+      switch (hd) {  // (hd 80 at L = 256 needs 182 KB of LDS: excluded above)
+        case 32: hipLaunchKernelGGL((attn_bwd_sp_kernel<32, 2>), g1, dim3(512), 0, (hipStream_t)stream, (const bf16*)qkv,
+                                    (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, H, sc, sl, L_valid); break;
+        case 64: hipLaunchKernelGGL((attn_bwd_sp_kernel<64, 2>), g1, dim3(512), 0, (hipStream_t)stream, (const bf16*)qkv,
+                                    (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, H, sc, sl, L_valid); break;
+        default: hipLaunchKernelGGL((attn_bwd_sp_kernel<72, 2>), g1, dim3(512), 0, (hipStream_t)stream, (const bf16*)qkv,
+                                    (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, H, sc, sl, L_valid); break;
+      }
+    }
+    return mdt_check_launch("attn_bwd_sp");
+  }
   dim3 grid(L / 64, B * H);
   ATTN_DISPATCH(hd, hipLaunchKernelGGL(attn_bwd_dq_kernel<HDc>, grid, dim3(256), 0, (hipStream_t)stream,
                                        (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta,

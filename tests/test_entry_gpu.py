@@ -38,6 +38,13 @@ def test_train_loop_checkpoint_and_resume(tmp_path):
     cfg = _cfg(tmp)
     out = T.train_loop(T.parse(['--config', cfg, '--results_dir', tmp, '--exp_name', 'a', '--max_num_steps', '6']))
     assert out['step'] == 6 and out['loss'] is not None and np.isfinite(out['loss'])
+    k = 'model.blocks.0.attn.qkv.weight'
+    live_net = dict(out['net'].named_parameters())[k].detach().cpu()
+    live_ema = dict(out['ema'].named_parameters())[k].detach().cpu()
+    print('live |net - ema| max', (live_net - live_ema).abs().max().item(), ' opt step', out['opt'].param_groups[0].get('step'),
+          ' lr', out['opt'].param_groups[0]['lr'], ' arena mode', out['opt']._arena is not None,
+          ' |G| max', out['net'].engine().G.abs().max().item(), ' |m| max', out['opt']._m.abs().max().item() if out['opt']._m is not None else None)
+    assert (live_net - live_ema).abs().max().item() > 1e-4, 'six optimizer steps at lr 1e-3 left the model on its EMA: nothing was trained'
     ck_dir = os.path.join(tmp, 'a', 'checkpoints')
     assert sorted(os.listdir(ck_dir)) == ['0000003.pt', '0000006.pt']  # train.py:259-271 naming
     ck = torch.load(os.path.join(ck_dir, '0000003.pt'), map_location='cpu', weights_only=False)

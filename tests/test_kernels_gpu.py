@@ -284,8 +284,10 @@ def test_gemm_tn_asymmetric_and_edges():
 
 
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('B_,L,H,hd', [(2, 128, 3, 72), (2, 256, 4, 32), (1, 128, 2, 64), (1, 64, 1, 80), (1, 512, 2, 72)])
-def test_attention_fwd_bwd(B_, L, H, hd):
+@pytest.mark.parametrize('B_,L,H,hd', [(2, 128, 3, 72), (2, 256, 4, 32), (1, 128, 2, 64), (1, 64, 1, 80), (1, 512, 2, 72),
+                                        (9, 128, 2, 80), (3, 256, 2, 72), (2, 256, 1, 64), (10, 128, 2, 32), (1, 256, 2, 80)])
+@pytest.mark.parametrize('sp', [0, 1, 2])  # 0: product dispatch (single-pass kernels at L <= 256), 1: block-loop kernels, 2: 1-WG/CU bwd
+def test_attention_fwd_bwd(B_, L, H, hd, sp):
     torch.manual_seed(3)
     D = H * hd
     qkv = bf(torch.randn(B_ * L, 3 * D, device=DEV))
@@ -293,7 +295,14 @@ def test_attention_fwd_bwd(B_, L, H, hd):
     q32 = qkv.float().reshape(B_, L, 3, H, hd).permute(2, 0, 3, 1, 4).contiguous().requires_grad_(True)
     o_ref = F.scaled_dot_product_attention(q32[0], q32[1], q32[2])
     o_ref2 = o_ref.transpose(1, 2).reshape(B_ * L, D)
-    out, lse = ops.attn_fwd(qkv, B_, L, H, hd)
+    if sp and L not in (128, 256):
+        pytest.skip('the knob only matters at L = 128 / 256')
+    _lib.lib().mdt_set_tuning(b'attn_sp', sp)
+    try:
+        out, lse = ops.attn_fwd(qkv, B_, L, H, hd)
+        dqkv = ops.attn_bwd(qkv, out, dout, lse, B_, L, H, hd)
+    finally:
+        _lib.lib().mdt_set_tuning(b'attn_sp', 0)
     close(out, o_ref2, 1e-2, f'attn fwd L{L} hd{hd}')
     # lse (log2 domain) check
     s = (q32[0] @ q32[1].transpose(-1, -2)) * hd ** -0.5
@@ -301,7 +310,6 @@ def test_attention_fwd_bwd(B_, L, H, hd):
     close(lse.reshape(B_, H, L), lse_ref, 1e-3, 'attn lse')
     o_ref2.backward(dout.float())
     dq_ref = q32.grad.permute(1, 3, 0, 2, 4).reshape(B_ * L, 3 * D)
-    dqkv = ops.attn_bwd(qkv, out, dout, lse, B_, L, H, hd)
     close(dqkv[:, :D], dq_ref[:, :D], 2e-2, 'attn dq')
     close(dqkv[:, D:2 * D], dq_ref[:, D:2 * D], 2e-2, 'attn dk')
     close(dqkv[:, 2 * D:], dq_ref[:, 2 * D:], 2e-2, 'attn dv')
@@ -333,11 +341,13 @@ def test_ln_modulate_fwd_bwd(B_, L, D):
     close(dx2, x.grad, 1e-4, 'ln_mod dx (overwrite)')
 
 
-def test_attention_padded_keys():
+@pytest.mark.parametrize('L,Lv,hd', [(192, 179, 64), (128, 100, 72), (256, 179, 32), (128, 65, 64), (256, 193, 72)])
+def test_attention_padded_keys(L, Lv, hd):
     """L_valid < L: rows >= L_valid are padding -- zero probability as keys; with dout = 0 on them the
-    whole dqkv of those rows is exactly zero and the valid rows match an attention over L_valid tokens."""
+    whole dqkv of those rows is exactly zero and the valid rows match an attention over L_valid tokens
+    (block-loop kernels at L = 192, single-pass kernels at L = 128 / 256)."""
     torch.manual_seed(41)
-    B_, L, H, hd, Lv = 3, 192, 6, 64, 179
+    B_, H = 3, 6
     D = H * hd
     qkv = bf(torch.randn(B_ * L, 3 * D, device=DEV) * 0.7)
     out, lse = ops.attn_fwd(qkv, B_, L, H, hd, L_valid=Lv)
