@@ -8,7 +8,7 @@ reference's Python surface:
     Losses['edm'] / EDMLoss, unwrap_model                        <- train_utils/loss.py, helper.py
     FusedAdam, update_ema                                        <- apex.optimizers, train_utils/helper.py
     edm_sampler                                                  <- sample.py
-    DataParallel                                                 <- accelerate / DDP (train.py:178)
+    DataParallel, ShardedFusedAdam (ZeRO-1)                      <- accelerate / DDP (train.py:178), train.py:226-230
     sample, class_dropout_                                       <- utils.py:59-65, train.py:208-209
     StackedRandomGenerator, seed_batches                         <- utils.py:119-133, sample.py:233-235
     data.{WdsTarLatents, LmdbLatents, LatentPrefetcher}          <- train_wds.py:58-97, train_utils/datasets.py:240-304
@@ -23,4 +23,5 @@ from .loss import EDMLoss, Losses, unwrap_model  # noqa: F401
 from .optim import FusedAdam, update_ema  # noqa: F401
 from .sampler import edm_sampler  # noqa: F401
 from .ddp import DataParallel, GradSlabReducer  # noqa: F401
+from .zero import ShardedFusedAdam  # noqa: F401
 from .latents import StackedRandomGenerator, class_dropout_, sample, seed_batches  # noqa: F401

@@ -633,13 +633,32 @@ __global__ __launch_bounds__(512) void attn_fwd_sp_kernel(const bf16* __restrict
   }
 }
 
-// OCC = waves per SIMD the register allocation aims at: 4 -> two workgroups per CU (<= 128 VGPRs, a few spills
-// outside the inner loops at hd >= 64), 2 -> one workgroup per CU, no spill ("attn_sp" = 2 selects it: A/B knob)
-template <int HD, int KF, int OCC = 4>
+// (sample, head) item -> coordinates, XCD-aware exactly like attn_block_coords (item i runs on XCD i % 8 when the
+// grid size is a multiple of 8: all heads of a sample then stay on one XCD's L2)
+__device__ __forceinline__ void sp_item_coords(int item, int B, int H, int& b, int& h) {
+  const int full = (B >> 3) << 3;
+  int sid;
+  if (item < full * H) {
+    const int xcd = item & 7, k = item >> 3;
+    const int grp = k / H;
+    sid = (grp * 8 + xcd) * H + (k - grp * H);
+  } else {
+    sid = item;
+  }
+  b = sid / H;
+  h = sid - b * H;
+}
+
+// OCC = waves per SIMD the register allocation aims at: 2 -> one workgroup per CU with the whole register file:
+// the kernel is then PERSISTENT (grid = #CUs, each workgroup walks (sample, head) items) and the global loads of item
+// i+1 -- four tiles, the O / dO rows for delta, lse -- are issued into registers right before the arithmetic of item i,
+// so the HBM round trip of every item but the first is hidden; 4 -> two workgroups per CU (<= 128 VGPRs, spills at
+// hd >= 64; measured slower: "attn_sp" = 2 selects it as an A/B knob), one item per workgroup.
+template <int HD, int KF, int OCC>
 __global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
-                                                          const bf16* __restrict__ dout, const float* __restrict__ lse,
-                                                          float* __restrict__ delta, bf16* __restrict__ dqkv, int H,
-                                                          float scale, float scale_log2e, int Lv) {
+                                                              const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                              float* __restrict__ delta, bf16* __restrict__ dqkv, int H,
+                                                              float scale, float scale_log2e, int Lv, int B) {
   using C = SpCfg<HD>;
   constexpr int L = 128 * KF;
   constexpr int TILE = L * C::PITCH;
@@ -652,163 +671,181 @@ __global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __res
   float* del_s = lse_s + L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i16 = lane & 15, g = lane >> 4;
-  int b, h;
-  sp_block_coords(gridDim.y / H, H, b, h);
-  const long bh = (long)b * H + h;
   const int D = H * HD;
   const long ld = 3L * D;
-  const bf16* base = qkv + (long)b * L * ld + h * HD;
-  const bf16* dobase = dout + (long)b * L * D + h * HD;
-  const bf16* obase = out + (long)b * L * D + h * HD;
+  const int nitems = B * H;
 
-  // ---- every global load up front: four tiles + this wave's O / dO rows for delta = rowsum(dO * O)
-  {
-    SpRegs<HD, L> r0, r1;
+  // ---- staged (in-register) copy of one item's inputs
+  SpRegs<HD, L> r0, r1, r2, r3;
+  bf16x8 of[KF][C::KSTEPS], dof[KF][C::KSTEPS];
+  float lse_r = 0.f;
+  auto fetch = [&](int item) {
+    int b, h;
+    sp_item_coords(item, B, H, b, h);
+    const bf16* base = qkv + (long)b * L * ld + h * HD;
+    const bf16* dobase = dout + (long)b * L * D + h * HD;
+    const bf16* obase = out + (long)b * L * D + h * HD;
     sp_load<HD, L>(r0, base, ld, tid);
     sp_load<HD, L>(r1, base + D, ld, tid);
-    SpRegs<HD, L> r2, r3;
     sp_load<HD, L>(r2, base + 2 * D, ld, tid);
     sp_load<HD, L>(r3, dobase, D, tid);
-    if (tid < L) lse_s[tid] = lse[bh * L + tid];
-    // delta: KF rows per lane-group of 16 lanes... one row per (wave, qi, i16); g splits the hd range
+    if (tid < L) lse_r = lse[((long)b * H + h) * L + tid];
 #pragma unroll
     for (int qi = 0; qi < KF; ++qi) {
       const int q = wave * 16 * KF + 16 * qi + i16;
-      bf16x8 of[C::KSTEPS], dof[C::KSTEPS];
-      load_frag_global<HD>(of, obase + (long)q * D, g);
-      load_frag_global<HD>(dof, dobase + (long)q * D, g);
+      load_frag_global<HD>(of[qi], obase + (long)q * D, g);
+      load_frag_global<HD>(dof[qi], dobase + (long)q * D, g);
+    }
+  };
+
+  int item = blockIdx.x;
+  if (item < nitems) fetch(item);
+  for (; item < nitems; item += gridDim.x) {
+    int b, h;
+    sp_item_coords(item, B, H, b, h);
+    const long bh = (long)b * H + h;
+    // ---- registers -> LDS (+ delta = rowsum(dO * O) of this wave's queries)
+    sp_store<HD, L>(r0, Qs, tid);
+    sp_store<HD, L>(r1, Ks, tid);
+    sp_store<HD, L>(r2, Vs, tid);
+    sp_store<HD, L>(r3, dOs, tid);
+    if (tid < L) lse_s[tid] = lse_r;
+#pragma unroll
+    for (int qi = 0; qi < KF; ++qi) {
+      const int q = wave * 16 * KF + 16 * qi + i16;
       float dl = 0.f;
 #pragma unroll
       for (int s = 0; s < C::KSTEPS; ++s)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dl += bf2f(dof[s][e]) * bf2f(of[s][e]);
+        for (int e = 0; e < 8; ++e) dl += bf2f(dof[qi][s][e]) * bf2f(of[qi][s][e]);
       dl = group_sum(dl);
       if (g == 0) {
         del_s[q] = dl;
         delta[bh * L + q] = dl;
       }
     }
-    sp_store<HD, L>(r0, Qs, tid);
-    sp_store<HD, L>(r1, Ks, tid);
-    sp_store<HD, L>(r2, Vs, tid);
-    sp_store<HD, L>(r3, dOs, tid);
-  }
-  __syncthreads();
+    __syncthreads();
+    // ---- the next item's loads fly under this item's arithmetic (persistent form only)
+    if (OCC == 2 && item + (int)gridDim.x < nitems) fetch(item + gridDim.x);
 
-  // ---- phase A: this wave's keys -> dK, dV (S fragments: rows = queries 16f + 4g + r, col = key i16)
+    // ---- phase A: this wave's keys -> dK, dV (S fragments: rows = queries 16f + 4g + r, col = key i16)
 #pragma unroll 1
-  for (int ki = 0; ki < KF; ++ki) {
-    const int k0 = wave * 16 * KF + 16 * ki;
-    bf16x8 kf[C::KSTEPS], vf[C::KSTEPS];
+    for (int ki = 0; ki < KF; ++ki) {
+      const int k0 = wave * 16 * KF + 16 * ki;
+      bf16x8 kf[C::KSTEPS], vf[C::KSTEPS];
 #pragma unroll
-    for (int ks = 0; ks < C::KSTEPS; ++ks) {
-      kf[ks] = sp_frag_rows<HD>(Ks, k0 + i16, ks, g);
-      vf[ks] = sp_frag_rows<HD>(Vs, k0 + i16, ks, g);
-    }
-    f32x4 dk[C::NFRAG], dv[C::NFRAG];
+      for (int ks = 0; ks < C::KSTEPS; ++ks) {
+        kf[ks] = sp_frag_rows<HD>(Ks, k0 + i16, ks, g);
+        vf[ks] = sp_frag_rows<HD>(Vs, k0 + i16, ks, g);
+      }
+      f32x4 dk[C::NFRAG], dv[C::NFRAG];
 #pragma unroll
-    for (int f = 0; f < C::NFRAG; ++f) {
-      dk[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      dv[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    const bool key_ok = (k0 + i16) < Lv;
+      for (int f = 0; f < C::NFRAG; ++f) {
+        dk[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dv[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      const bool key_ok = (k0 + i16) < Lv;
 #pragma unroll 1
-    for (int qb = 0; qb < L; qb += 64) {
-      f32x4 pm[4], ds[4];
+      for (int qb = 0; qb < L; qb += 64) {
+        f32x4 pm[4], ds[4];
 #pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int f = 0; f < 4; ++f) {
+          f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < C::KSTEPS; ++ks) {
-          s = mfma16(sp_frag_rows<HD>(Qs, qb + 16 * f + i16, ks, g), kf[ks], s);
-          dp = mfma16(sp_frag_rows<HD>(dOs, qb + 16 * f + i16, ks, g), vf[ks], dp);
+          for (int ks = 0; ks < C::KSTEPS; ++ks) {
+            s = mfma16(sp_frag_rows<HD>(Qs, qb + 16 * f + i16, ks, g), kf[ks], s);
+            dp = mfma16(sp_frag_rows<HD>(dOs, qb + 16 * f + i16, ks, g), vf[ks], dp);
+          }
+          const f32x4 ls = *(const f32x4*)(lse_s + qb + 16 * f + 4 * g);
+          const f32x4 dl = *(const f32x4*)(del_s + qb + 16 * f + 4 * g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = key_ok ? fast_exp2(s[r] * scale_log2e - ls[r]) : 0.f;
+            pm[f][r] = pv;
+            ds[f][r] = pv * (dp[r] - dl[r]) * scale;
+          }
         }
-        const f32x4 ls = *(const f32x4*)(lse_s + qb + 16 * f + 4 * g);
-        const f32x4 dl = *(const f32x4*)(del_s + qb + 16 * f + 4 * g);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = key_ok ? exp2f(s[r] * scale_log2e - ls[r]) : 0.f;
-          pm[f][r] = pv;
-          ds[f][r] = pv * (dp[r] - dl[r]) * scale;
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 pf = pack_pair(pm[2 * ks], pm[2 * ks + 1]);
+          const bf16x8 dsf = pack_pair(ds[2 * ks], ds[2 * ks + 1]);
+#pragma unroll
+          for (int f = 0; f < C::NFRAG; ++f) {
+            dv[f] = mfma16(sp_frag_cols<HD>(dOs, qb + 32 * ks, f, i16, g), pf, dv[f]);
+            dk[f] = mfma16(sp_frag_cols<HD>(Qs, qb + 32 * ks, f, i16, g), dsf, dk[f]);
+          }
         }
       }
+      bf16* drow = dqkv + ((long)b * L + k0 + i16) * ld + h * HD;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 pf = pack_pair(pm[2 * ks], pm[2 * ks + 1]);
-        const bf16x8 dsf = pack_pair(ds[2 * ks], ds[2 * ks + 1]);
+      for (int f = 0; f < C::NFRAG; ++f) {
+        const int d = 16 * f + 4 * g;
+        if (d < HD) {
+          bf16x4 a, c;
 #pragma unroll
-        for (int f = 0; f < C::NFRAG; ++f) {
-          dv[f] = mfma16(sp_frag_cols<HD>(dOs, qb + 32 * ks, f, i16, g), pf, dv[f]);
-          dk[f] = mfma16(sp_frag_cols<HD>(Qs, qb + 32 * ks, f, i16, g), dsf, dk[f]);
+          for (int r = 0; r < 4; ++r) {
+            a[r] = f2bf(dk[f][r]);
+            c[r] = f2bf(dv[f][r]);
+          }
+          *(bf16x4*)(drow + D + d) = a;
+          *(bf16x4*)(drow + 2 * D + d) = c;
         }
       }
     }
-    bf16* drow = dqkv + ((long)b * L + k0 + i16) * ld + h * HD;
-#pragma unroll
-    for (int f = 0; f < C::NFRAG; ++f) {
-      const int d = 16 * f + 4 * g;
-      if (d < HD) {
-        bf16x4 a, c;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          a[r] = f2bf(dk[f][r]);
-          c[r] = f2bf(dv[f][r]);
-        }
-        *(bf16x4*)(drow + D + d) = a;
-        *(bf16x4*)(drow + 2 * D + d) = c;
-      }
-    }
-  }
 
-  // ---- phase B: this wave's queries -> dQ (S^T fragments: rows = keys 16f + 4g + r, col = query i16)
+    // ---- phase B: this wave's queries -> dQ (S^T fragments: rows = keys 16f + 4g + r, col = query i16)
 #pragma unroll 1
-  for (int qi = 0; qi < KF; ++qi) {
-    const int q = wave * 16 * KF + 16 * qi + i16;
-    bf16x8 qf[C::KSTEPS], dof[C::KSTEPS];
+    for (int qi = 0; qi < KF; ++qi) {
+      const int q = wave * 16 * KF + 16 * qi + i16;
+      bf16x8 qf[C::KSTEPS], dqo[C::KSTEPS];
 #pragma unroll
-    for (int ks = 0; ks < C::KSTEPS; ++ks) {
-      qf[ks] = sp_frag_rows<HD>(Qs, q, ks, g);
-      dof[ks] = sp_frag_rows<HD>(dOs, q, ks, g);
-    }
-    const float my_lse = lse_s[q], dl = del_s[q];
-    f32x4 dq[C::NFRAG];
+      for (int ks = 0; ks < C::KSTEPS; ++ks) {
+        qf[ks] = sp_frag_rows<HD>(Qs, q, ks, g);
+        dqo[ks] = sp_frag_rows<HD>(dOs, q, ks, g);
+      }
+      const float my_lse = lse_s[q], dl = del_s[q];
+      f32x4 dq[C::NFRAG];
 #pragma unroll
-    for (int f = 0; f < C::NFRAG; ++f) dq[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int f = 0; f < C::NFRAG; ++f) dq[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-    for (int kb = 0; kb < L; kb += 64) {
-      f32x4 ds[4];
+      for (int kb = 0; kb < L; kb += 64) {
+        f32x4 ds[4];
 #pragma unroll
-      for (int f = 0; f < 4; ++f) {
-        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int f = 0; f < 4; ++f) {
+          f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ks = 0; ks < C::KSTEPS; ++ks) {
-          s = mfma16(sp_frag_rows<HD>(Ks, kb + 16 * f + i16, ks, g), qf[ks], s);
-          dp = mfma16(sp_frag_rows<HD>(Vs, kb + 16 * f + i16, ks, g), dof[ks], dp);
+          for (int ks = 0; ks < C::KSTEPS; ++ks) {
+            s = mfma16(sp_frag_rows<HD>(Ks, kb + 16 * f + i16, ks, g), qf[ks], s);
+            dp = mfma16(sp_frag_rows<HD>(Vs, kb + 16 * f + i16, ks, g), dqo[ks], dp);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = (kb + 16 * f + 4 * g + r < Lv) ? fast_exp2(s[r] * scale_log2e - my_lse) : 0.f;
+            ds[f][r] = pv * (dp[r] - dl) * scale;
+          }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = (kb + 16 * f + 4 * g + r < Lv) ? exp2f(s[r] * scale_log2e - my_lse) : 0.f;
-          ds[f][r] = pv * (dp[r] - dl) * scale;
+        for (int ks = 0; ks < 2; ++ks) {
+          const bf16x8 dsf = pack_pair(ds[2 * ks], ds[2 * ks + 1]);
+#pragma unroll
+          for (int f = 0; f < C::NFRAG; ++f) dq[f] = mfma16(sp_frag_cols<HD>(Ks, kb + 32 * ks, f, i16, g), dsf, dq[f]);
         }
       }
+      bf16* drow = dqkv + ((long)b * L + q) * ld + h * HD;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 dsf = pack_pair(ds[2 * ks], ds[2 * ks + 1]);
+      for (int f = 0; f < C::NFRAG; ++f) {
+        const int d = 16 * f + 4 * g;
+        if (d < HD) {
+          bf16x4 v;
 #pragma unroll
-        for (int f = 0; f < C::NFRAG; ++f) dq[f] = mfma16(sp_frag_cols<HD>(Ks, kb + 32 * ks, f, i16, g), dsf, dq[f]);
+          for (int r = 0; r < 4; ++r) v[r] = f2bf(dq[f][r]);
+          *(bf16x4*)(drow + d) = v;
+        }
       }
     }
-    bf16* drow = dqkv + ((long)b * L + q) * ld + h * HD;
-#pragma unroll
-    for (int f = 0; f < C::NFRAG; ++f) {
-      const int d = 16 * f + 4 * g;
-      if (d < HD) {
-        bf16x4 v;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = f2bf(dq[f][r]);
-        *(bf16x4*)(drow + d) = v;
-      }
-    }
+    if (OCC != 2) break;  // one item per workgroup
+    __syncthreads();      // every wave is done with the tiles before the next item overwrites them
+    if (OCC == 2 && !(item + (int)gridDim.x < nitems)) break;
   }
 }
 
@@ -864,24 +901,33 @@ extern "C" int mdt_attn_bwd(const mdt_bf16* qkv, const mdt_bf16* out, const mdt_
   if (L_valid <= 0 || L_valid > L) L_valid = L;
   float sc = 1.0f / sqrtf((float)hd);
   float sl = sc * 1.4426950408889634f;
-  if ((L == 128 || (L == 256 && (hd == 32 || hd == 64 || hd == 72))) && mdt_get_tuning_int(MDT_TUNE_ATTN_SP) != 1) {
-    dim3 g1(1, B * H);
-    if (L == 128 && mdt_get_tuning_int(MDT_TUNE_ATTN_SP) == 2) {
-      ATTN_DISPATCH(hd, hipLaunchKernelGGL((attn_bwd_sp_kernel<HDc, 1, 2>), g1, dim3(512), 0, (hipStream_t)stream,
+  // Short sequences: dQ, dK, dV in ONE launch (attn_bwd_sp_kernel).  Measured on MI355X at the benchmarked shapes
+  // (tools/attn_bench.py): L = 128 / hd 72: 888 us vs 1091 us for the two block-loop kernels with one workgroup per CU
+  // (OCC = 2; the <= 128-VGPR two-per-CU build spills and is slower, 1153 us); L = 256 / hd 32 is bound by the
+  // softmax-recompute VALU work and ties (1381 vs 1375 us), so it stays on the block-loop kernels.
+  // "attn_sp": 0 = this default, 1 = block-loop kernels everywhere, 2 = single-pass wherever instantiated, OCC = 4.
+  const int sp_knob = mdt_get_tuning_int(MDT_TUNE_ATTN_SP);
+  const bool sp_ok = L == 128 || (L == 256 && (hd == 32 || hd == 64 || hd == 72));  // (hd 80 at L = 256: 182 KB of LDS)
+  if (sp_ok && sp_knob != 1 && (L == 128 || sp_knob == 2)) {
+    dim3 g1(B * H);                                   // OCC = 4: one item per workgroup
+    const int items = B * H;
+    dim3 gp(items < 256 ? items : 256);              // OCC = 2: persistent, one workgroup per CU (multiple of 8: XCD affinity)
+    if (L == 128 && sp_knob == 2) {
+      ATTN_DISPATCH(hd, hipLaunchKernelGGL((attn_bwd_sp_kernel<HDc, 1, 4>), g1, dim3(512), 0, (hipStream_t)stream,
                                            (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, H,
-                                           sc, sl, L_valid));
+                                           sc, sl, L_valid, B));
     } else if (L == 128) {
-      ATTN_DISPATCH(hd, hipLaunchKernelGGL((attn_bwd_sp_kernel<HDc, 1>), g1, dim3(512), 0, (hipStream_t)stream,
+      ATTN_DISPATCH(hd, hipLaunchKernelGGL((attn_bwd_sp_kernel<HDc, 1, 2>), gp, dim3(512), 0, (hipStream_t)stream,
                                            (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, H,
-                                           sc, sl, L_valid));
+                                           sc, sl, L_valid, B));
     } else {
-      switch (hd) {  // (hd 80 at L = 256 needs 182 KB of LDS: excluded above)
-        case 32: hipLaunchKernelGGL((attn_bwd_sp_kernel<32, 2>), g1, dim3(512), 0, (hipStream_t)stream, (const bf16*)qkv,
-                                    (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, H, sc, sl, L_valid); break;
-        case 64: hipLaunchKernelGGL((attn_bwd_sp_kernel<64, 2>), g1, dim3(512), 0, (hipStream_t)stream, (const bf16*)qkv,
-                                    (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, H, sc, sl, L_valid); break;
-        default: hipLaunchKernelGGL((attn_bwd_sp_kernel<72, 2>), g1, dim3(512), 0, (hipStream_t)stream, (const bf16*)qkv,
-                                    (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, H, sc, sl, L_valid); break;
+      switch (hd) {
+        case 32: hipLaunchKernelGGL((attn_bwd_sp_kernel<32, 2, 2>), gp, dim3(512), 0, (hipStream_t)stream, (const bf16*)qkv,
+                                    (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, H, sc, sl, L_valid, B); break;
+        case 64: hipLaunchKernelGGL((attn_bwd_sp_kernel<64, 2, 2>), gp, dim3(512), 0, (hipStream_t)stream, (const bf16*)qkv,
+                                    (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, H, sc, sl, L_valid, B); break;
+        default: hipLaunchKernelGGL((attn_bwd_sp_kernel<72, 2, 2>), gp, dim3(512), 0, (hipStream_t)stream, (const bf16*)qkv,
+                                    (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, H, sc, sl, L_valid, B); break;
       }
     }
     return mdt_check_launch("attn_bwd_sp");

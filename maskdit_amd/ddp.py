@@ -30,25 +30,45 @@ class GradSlabReducer:
     def __init__(self, process_group=None, bucket_elems: int = 0):
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         self.backend = dist.get_backend(process_group) if dist.is_initialized() else None
         self.pending: List = []
         self.flat: Optional[torch.Tensor] = None
         self.enabled = True  # False inside no_sync() (gradient accumulation micro-steps)
         self.reduced_elems = 0
+        self.shard_bounds: Optional[List[int]] = None  # ZeRO-1: rank r owns arena elements [b[r], b[r+1])
 
     def attach(self, flat_grad: torch.Tensor):
         self.flat = flat_grad
 
+    def set_owner_shards(self, bounds: List[int]):
+        """ZeRO-1 (maskdit_amd/zero.py): every gradient range is reduced TO THE RANK THAT OWNS ITS OPTIMIZER STATE
+        instead of all-reduced -- half the bytes on the links; the other half is the all-gather of the updated
+        parameters after the sharded optimizer step."""
+        assert len(bounds) == self.world + 1 and bounds[0] == 0 and all(a <= b for a, b in zip(bounds, bounds[1:]))
+        self.shard_bounds = list(bounds)
+
+    def _reduce_piece(self, chunk: torch.Tensor, dst: Optional[int]):
+        avg = self.backend == 'nccl'
+        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM  # gloo has no AVG: divide after the wait
+        if dst is None:
+            work = dist.all_reduce(chunk, op=op, group=self.pg, async_op=True)
+            self.pending.append((work, None if avg else chunk))
+        else:
+            work = dist.reduce(chunk, dst=dst, op=op, group=self.pg, async_op=True)
+            self.pending.append((work, chunk if (not avg and dst == self.rank) else None))
+
     def reduce_range(self, name: str, lo: int, hi: int):
         if self.world == 1 or not self.enabled or hi <= lo:
             return
-        chunk = self.flat[lo:hi]
-        if self.backend == 'nccl':
-            work = dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.pg, async_op=True)
-            self.pending.append((work, None))
-        else:  # gloo has no AVG
-            work = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
-            self.pending.append((work, chunk))
+        if self.shard_bounds is None:
+            self._reduce_piece(self.flat[lo:hi], None)
+        else:  # split the slab at the ownership boundaries: one reduce per owner
+            b = self.shard_bounds
+            for r in range(self.world):
+                a, e = max(lo, b[r]), min(hi, b[r + 1])
+                if a < e:
+                    self._reduce_piece(self.flat[a:e], r)
         self.reduced_elems += hi - lo
 
     def finish(self):
@@ -59,16 +79,40 @@ class GradSlabReducer:
         self.pending.clear()
 
 
+def reserve_cus_for_collectives(n_reserved: int) -> int:
+    """The persistent GEMM kernels launch exactly one workgroup per CU and each takes the CU's whole register file
+    and 112-128 KiB of its LDS: an RCCL all-reduce kernel that becomes resident in the middle of the backward pass
+    would leave some of those persistent workgroups waiting for a CU (every GEMM launch would then take two
+    rounds), and conversely RCCL could not start while a GEMM holds every CU.  With data parallelism active the
+    GEMM grids are therefore capped at (CUs - n_reserved) (`mdt_set_tuning("nt8_max_cus")`), which leaves
+    `n_reserved` CUs to the collective for the whole backward.  Cost of the reservation on one GPU: tools/nt8_bench.py
+    column "240 CUs" (GEMM time scales with 256 / (256 - n_reserved))."""
+    from . import _lib
+    import torch
+    cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    cap = max(cus - max(int(n_reserved), 0), cus // 2)
+    _lib.check(_lib.lib().mdt_set_tuning(b'nt8_max_cus', cap if n_reserved > 0 else 0), 'mdt_set_tuning')
+    return cap
+
+
 class DataParallel(nn.Module):
     """`.module` holds the EDMPrecond (train_utils/loss.py:47 dereferences `net.module`).
     Construction broadcasts rank 0's parameter arena (what DDP does in `accelerator.prepare`,
     train.py:178).  Forward simply delegates; the loss object runs the fused path on
-    `.module` and the gradient slabs flow through `GradSlabReducer`."""
+    `.module` and the gradient slabs flow through `GradSlabReducer`.
 
-    def __init__(self, module: nn.Module, process_group=None):
+    `rccl_cus` (default: env MDT_RCCL_CUS or 16; only with the nccl backend and world > 1): CUs kept free of the
+    persistent GEMM workgroups so that the slab all-reduces really run under the backward kernels
+    (reserve_cus_for_collectives)."""
+
+    def __init__(self, module: nn.Module, process_group=None, rccl_cus=None):
         super().__init__()
         self.module = module
         self.reducer = GradSlabReducer(process_group)
+        if self.reducer.world > 1 and self.reducer.backend == 'nccl':
+            import os
+            self.reserved_cus = int(os.environ.get('MDT_RCCL_CUS', '16')) if rccl_cus is None else int(rccl_cus)
+            self.gemm_cus = reserve_cus_for_collectives(self.reserved_cus)
         eng = module.engine()
         if self.reducer.world > 1:
             dist.broadcast(eng.P, src=0, group=process_group)

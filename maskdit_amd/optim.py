@@ -73,11 +73,17 @@ class FusedAdam(torch.optim.Optimizer):
         if want == have:
             self._first = trainable[0]
             self._arena = eng
-            dev = eng.P.device
-            if self._m is None or self._m.numel() != eng.lay.n or self._m.device != dev:
-                self._m = torch.zeros(eng.lay.n, device=dev, dtype=torch.float32)
-                self._v = torch.zeros(eng.lay.n, device=dev, dtype=torch.float32)
-                for p in trainable:
+            self._alloc_moments(eng)
+
+    def _alloc_moments(self, eng):
+        """Moment arenas of the engine's layout + apex-style per-parameter views (ShardedFusedAdam overrides)."""
+        dev = eng.P.device
+        base = eng.P.data_ptr()
+        if self._m is None or self._m.numel() != eng.lay.n or self._m.device != dev:
+            self._m = torch.zeros(eng.lay.n, device=dev, dtype=torch.float32)
+            self._v = torch.zeros(eng.lay.n, device=dev, dtype=torch.float32)
+            for p in self.param_groups[0]['params']:
+                if p.requires_grad:
                     off = (p.data_ptr() - base) // 4
                     self.state[p] = {'exp_avg': self._m[off:off + p.numel()].view_as(p),
                                      'exp_avg_sq': self._v[off:off + p.numel()].view_as(p)}

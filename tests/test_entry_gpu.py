@@ -47,6 +47,10 @@ def test_train_loop_checkpoint_and_resume(tmp_path):
     assert (live_net - live_ema).abs().max().item() > 1e-4, 'six optimizer steps at lr 1e-3 left the model on its EMA: nothing was trained'
     ck_dir = os.path.join(tmp, 'a', 'checkpoints')
     assert sorted(os.listdir(ck_dir)) == ['0000003.pt', '0000006.pt']  # train.py:259-271 naming
+    ck6 = torch.load(os.path.join(ck_dir, '0000006.pt'), map_location='cpu', weights_only=False)
+    print('ck6 model == live net', torch.equal(ck6['model'][k], live_net), ' ck6 ema == live ema', torch.equal(ck6['ema'][k], live_ema),
+          ' ck6 ema == live net', torch.equal(ck6['ema'][k], live_net), ' file MB', os.path.getsize(os.path.join(ck_dir, '0000006.pt')) / 2**20)
+    assert torch.equal(ck6['model'][k], live_net) and torch.equal(ck6['ema'][k], live_ema)
     ck = torch.load(os.path.join(ck_dir, '0000003.pt'), map_location='cpu', weights_only=False)
     assert set(ck) == {'model', 'ema', 'opt', 'args'} and ck['opt']['param_groups'][0]['step'] == 3
     # after 3 steps with decay 0.9999 the EMA is close to, but not equal to, the model

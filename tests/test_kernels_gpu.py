@@ -286,7 +286,7 @@ def test_gemm_tn_asymmetric_and_edges():
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('B_,L,H,hd', [(2, 128, 3, 72), (2, 256, 4, 32), (1, 128, 2, 64), (1, 64, 1, 80), (1, 512, 2, 72),
                                         (9, 128, 2, 80), (3, 256, 2, 72), (2, 256, 1, 64), (10, 128, 2, 32), (1, 256, 2, 80)])
-@pytest.mark.parametrize('sp', [0, 1, 2])  # 0: product dispatch (single-pass kernels at L <= 256), 1: block-loop kernels, 2: 1-WG/CU bwd
+@pytest.mark.parametrize('sp', [0, 1, 2])  # 0: product dispatch, 1: block-loop kernels everywhere, 2: single-pass everywhere (2 WG/CU bwd build)
 def test_attention_fwd_bwd(B_, L, H, hd, sp):
     torch.manual_seed(3)
     D = H * hd

@@ -32,7 +32,7 @@ def main(iters=20):
     # the benchmarked shapes: encoder (B 1024, L 128, hd 72) and decoder (B 1024, T 256, hd 32) of XL/2 at 256^2
     for B, L, H, hd in [(1024, 128, 16, 72), (1024, 256, 16, 32), (64, 512, 16, 72), (128, 256, 16, 72)]:
         qkv = (torch.randn(B * L, 3 * H * hd, device=dev) * 0.5).to(torch.bfloat16)
-        for sp, name in ((1, 'block-loop'), (0, 'single-pass'), (2, 'sp 1WG/CU')):
+        for sp, name in ((1, 'block-loop'), (0, 'default'), (2, 'sp OCC=4')):
             if sp != 1 and L not in (128, 256):
                 continue
             L_.mdt_set_tuning(b'attn_sp', sp)
