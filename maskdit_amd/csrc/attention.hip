@@ -860,6 +860,17 @@ __global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __res
     default: mdt_set_error("attention: head_dim must be one of 32, 64, 72, 80"); return MDT_ERR_ARG; \
   }
 
+static int attn_num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
 extern "C" int mdt_attn_fwd(const mdt_bf16* qkv, mdt_bf16* out, float* lse, int B, int L, int H, int hd, int L_valid,
                             mdt_stream_t stream) {
   MDT_REQUIRE(qkv && out && lse, "attn_fwd: null pointer");
@@ -903,15 +914,16 @@ extern "C" int mdt_attn_bwd(const mdt_bf16* qkv, const mdt_bf16* out, const mdt_
   float sl = sc * 1.4426950408889634f;
   // Short sequences: dQ, dK, dV in ONE launch (attn_bwd_sp_kernel).  Measured on MI355X at the benchmarked shapes
   // (tools/attn_bench.py): L = 128 / hd 72: 888 us vs 1091 us for the two block-loop kernels with one workgroup per CU
-  // (OCC = 2; the <= 128-VGPR two-per-CU build spills and is slower, 1153 us); L = 256 / hd 32 is bound by the
-  // softmax-recompute VALU work and ties (1381 vs 1375 us), so it stays on the block-loop kernels.
-  // "attn_sp": 0 = this default, 1 = block-loop kernels everywhere, 2 = single-pass wherever instantiated, OCC = 4.
+  // per CU, persistent, next-item prefetch (809 us; the <= 128-VGPR two-per-CU build spills: 953 us); L = 256 / hd 32
+  // (decoder): 1059 vs 1347 us; L = 256 / hd 72 needs 150 KB of LDS and spills -- it stays on the block-loop kernels.
+  // "attn_sp": 0 = this default, 1 = block-loop kernels everywhere, 2 = single-pass wherever instantiated (OCC = 4 at L = 128).
   const int sp_knob = mdt_get_tuning_int(MDT_TUNE_ATTN_SP);
   const bool sp_ok = L == 128 || (L == 256 && (hd == 32 || hd == 64 || hd == 72));  // (hd 80 at L = 256: 182 KB of LDS)
-  if (sp_ok && sp_knob != 1 && (L == 128 || sp_knob == 2)) {
+  if (sp_ok && sp_knob != 1 && (L == 128 || hd <= 64 || sp_knob == 2)) {
     dim3 g1(B * H);                                   // OCC = 4: one item per workgroup
     const int items = B * H;
-    dim3 gp(items < 256 ? items : 256);              // OCC = 2: persistent, one workgroup per CU (multiple of 8: XCD affinity)
+    const int cus = attn_num_cus();
+    dim3 gp(items < cus ? items : cus);              // OCC = 2: persistent, one workgroup per CU (multiple of 8: XCD affinity)
     if (L == 128 && sp_knob == 2) {
       ATTN_DISPATCH(hd, hipLaunchKernelGGL((attn_bwd_sp_kernel<HDc, 1, 4>), g1, dim3(512), 0, (hipStream_t)stream,
                                            (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, H,

@@ -41,22 +41,24 @@ static __device__ float nt8_zero_row[NT8_ZERO_ROW + 64];  // zero-initialised; o
 
 namespace nt8 {
 
-enum { E_PLAIN = 0, E_F32 = 1, E_ACT = 2, E_GATE = 3, E_DACT = 4 };
+enum { E_PLAIN = 0, E_F32 = 1, E_ACT = 2, E_GATE = 3, E_DACT = 4,
+       E_TRK = 5 };  // E_TRK: overlap EXPERIMENT (tools/nt8_bench.py): GATE-sized epilogue traffic issued one 16-byte op per
+                     // phase inside the K loop instead of after it (results are garbage; timing only)
 
 // loads issued per wave in phase p: one A slot + RPP B rounds while p < NF (RPP = 1 with 8 waves,
 // 2 with 4 waves: half as many waves share the same B tile)
 constexpr int c_issue(int p, int NF, int RPP) { return 1 + (p < NF ? RPP : 0); }
 
 // steady-state vmcnt operand at the end of phase p (see header)
-constexpr int wait_count(int p, int NF, int RPP) {
+constexpr int wait_count(int p, int NF, int RPP, int trk = 0) {
   // next phase (g+1) prefetches A slot (p+2)&3 [of the current or the next K-tile], issued at
   // phase g-6 whose phase index is (p+2)&3; the B instruction of that phase was issued after it.
   int w = (((p + 2) & 3) < NF) ? RPP : 0;
-  for (int d = 5; d >= 0; --d) w += c_issue(((p - d) % 4 + 4) % 4, NF, RPP);
+  for (int d = 5; d >= 0; --d) w += c_issue(((p - d) % 4 + 4) % 4, NF, RPP) + trk;  // trk extra ops per phase (E_TRK)
   if (p == 2) {
     // phase 3 also reads the whole next-tile B: its last instruction was issued at phase NF-1 of
     // the previous K-tile; after it: one A load per phase NF..3, then phases 0..2 of this tile
-    int wb = (4 - NF) + c_issue(0, NF, RPP) + c_issue(1, NF, RPP) + c_issue(2, NF, RPP);
+    int wb = (4 - NF) + c_issue(0, NF, RPP) + c_issue(1, NF, RPP) + c_issue(2, NF, RPP) + trk * ((4 - NF) + 3);
     if (wb < w) w = wb;
   }
   return w;
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
   constexpr int A_BYTES = BM8 * 128;
   constexpr int STAGE = A_BYTES + BN8 * 128;
   constexpr int WN = 16 * NF;
-  constexpr int LDS_BYTES = 2 * STAGE;
+  constexpr int LDS_BYTES = 2 * STAGE + (E == E_TRK ? 8192 : 0);  // E_TRK: 1 KiB per wave of DMA scratch
   static_assert(LDS_BYTES * (WR == 2 ? 1 : 2) <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES];
 
@@ -201,6 +203,16 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
         glds16(b_u + (long)kt * 128 + opaque(b_lo[ph * RPP + r]), base + b_lds0 + (ph * RPP + r) * (BROWS * 128));
       }
     }
+  };
+
+  // E_TRK: one 16-byte-per-lane memory operation per phase, alternating an fp32 store into this tile's outf rows
+  // and an LDS-DMA load from its res rows (together ~ the bytes of a GATE_RES epilogue spread over a K = 1152 loop)
+  auto trickle = [&](int slot, f32x4 v) {
+    const int u = slot >> 1, band = u & 7, j = (u >> 3) % NF;  // the epilogue's (band, fragment) walk
+    const long off = (long)(m0 + (wave >> 2) * 128 + band * 16 + (lane & 15)) * p.ldof + n0 + (wave & 3) * (16 * NF) + 16 * j +
+                     4 * (lane >> 4);
+    if (slot & 1) glds16(p.res + off, smem + 2 * STAGE + wave * 1024);
+    else *(f32x4*)(p.outf + off) = v;
   };
 
   // ---- fragment read offsets (bytes inside a stage); row & 7 == fr & 7 for every fragment
@@ -294,6 +306,7 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
       }                                                                                               \
       /* (2) refill the slot whose reads retired before the previous barrier */                       \
       if (!DRAIN) issue(half, kt + half + 2, ph);                                                     \
+      if (E == E_TRK && !DRAIN) trickle((kt + half) * 4 + ph, acc[2 * ph][0]);                        \
       /* (3) this phase's MFMAs */                                                                    \
       __builtin_amdgcn_s_setprio(1);                                                                  \
       _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                              \
@@ -316,10 +329,10 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
         else if (half == 1 && ph == 1) wait_vm_lgkm<drain_count(5, NF, RPP)>();                       \
         else wait_vm_lgkm<0>();                                                                       \
       }                                                                                               \
-      else if (ph == 0) wait_vm_lgkm<wait_count(0, NF, RPP)>();                                       \
-      else if (ph == 1) wait_vm_lgkm<wait_count(1, NF, RPP)>();                                       \
-      else if (ph == 2) wait_vm_lgkm<wait_count(2, NF, RPP)>();                                       \
-      else wait_vm_lgkm<wait_count(3, NF, RPP)>();                                                    \
+      else if (ph == 0) wait_vm_lgkm<wait_count(0, NF, RPP, E == E_TRK)>();                           \
+      else if (ph == 1) wait_vm_lgkm<wait_count(1, NF, RPP, E == E_TRK)>();                           \
+      else if (ph == 2) wait_vm_lgkm<wait_count(2, NF, RPP, E == E_TRK)>();                           \
+      else wait_vm_lgkm<wait_count(3, NF, RPP, E == E_TRK)>();                                        \
       __builtin_amdgcn_s_barrier();                                                                   \
       asm volatile("" ::: "memory");                                                                  \
     }                                                                                                 \
@@ -347,7 +360,7 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
     for (int ph = 0; ph < 4; ++ph) issue(1, 1, ph);
   }
 
-  if (p.epi & 0x100) {  // benchmarking aid (mdt_set_tuning "nt8_skip_epilogue"): main loop only
+  if ((p.epi & 0x100) || E == E_TRK) {  // benchmarking aid (mdt_set_tuning "nt8_skip_epilogue"): main loop only
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll

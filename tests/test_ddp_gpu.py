@@ -152,44 +152,59 @@ def _zero_worker(rank, world, port, q):
             md = M.get_mask(sl.stop - sl.start, 256, 0.5, dev, noise=mnoise[s, sl].to(dev))
             return loss_fn.with_draws(model, images[s, sl].to(dev), labels[s, sl].to(dev), rnd[s, sl].to(dev), noise[s, sl].to(dev), md, 0.1)
 
-        # ---- sharded: 2 ranks x half batches
+        # ---- sharded run next to an unsharded reference that is fed the SAME averaged gradient: plain FusedAdam on a
+        # second replica whose gradient arena is filled from the owners' reduced ranges.  Same kernel per element =>
+        # bit-identical parameters, EMA and moments.  (Recomputing the gradient from the full batch instead would
+        # differ by fp32-atomics noise, which Adam's m / (sqrt(v) + eps) amplifies to O(lr) where |g| is tiny.)
         net = build()
         ema = copy.deepcopy(net).eval()
         dp = M.DataParallel(net)
         opt = M.ShardedFusedAdam(net.parameters(), data_parallel=dp, lr=1e-3)
         assert opt._m.numel() <= net.engine().lay.n // world + 8, 'moments are not sharded'
         opt.fuse_ema(ema, 0.99)
-        half = slice(rank * B // 2, (rank + 1) * B // 2)
-        for s in range(2):
-            opt.zero_grad(set_to_none=True)
-            run(dp, s, half).mean().backward()
-            dp.finish_grad_sync()
-            opt.step()
-            M.update_ema(ema, net, 0.99)
-        opt.sync_ema()
-        sd = opt.state_dict()
-        # ---- unsharded single-process reference on the full batch (every rank computes it; same kernels)
         ref = build()
         ref_ema = copy.deepcopy(ref).eval()
         ropt = M.FusedAdam(ref.parameters(), lr=1e-3)
         ropt.fuse_ema(ref_ema, 0.99)
+        half = slice(rank * B // 2, (rank + 1) * B // 2)
+        bounds = opt._bounds
         for s in range(2):
+            opt.zero_grad(set_to_none=True)
+            run(dp, s, half).mean().backward()
+            dp.finish_grad_sync()
+            # the averaged gradient, assembled from the owners (each rank holds the reduced values of its own range only)
+            G = net.engine().G
+            Gfull = G.detach().clone()
+            for r in range(world):
+                if bounds[r] < bounds[r + 1]:
+                    dist.broadcast(Gfull[bounds[r]:bounds[r + 1]], src=r)
+            lo, hi = bounds[rank], bounds[rank + 1]
+            assert torch.equal(Gfull[lo:hi], G[lo:hi])
             ropt.zero_grad(set_to_none=True)
-            run(ref, s, slice(0, B)).mean().backward()
+            ref._prepare_grad_arena()
+            ref.engine().G.copy_(Gfull)
+            opt.step()
+            M.update_ema(ema, net, 0.99)
             ropt.step()
             M.update_ema(ref_ema, ref, 0.99)
+        # sanity of the reduce-to-owner gradient itself: equals the full-batch gradient within atomics noise
+        ref2 = build()
+        run(ref2, 1, slice(0, B)).mean().backward()
+        gf = ref2.engine().G
+        relg = ((Gfull - gf).norm() / gf.norm()).item()
+        assert relg <= 5e-3, f'reduce-to-owner gradient differs from the full-batch gradient ({relg:.3e})'
+        opt.sync_ema()
+        sd = opt.state_dict()
         rsd = ropt.state_dict()
-        worst = 0.0
+        worst = relg
         for (k, a), (_, b) in zip(net.named_parameters(), ref.named_parameters()):
-            if a.requires_grad:
-                d = (a - b).abs().max().item()
-                worst = max(worst, d)
-                assert d <= 1e-4, f'{k}: sharded step differs from the unsharded one by {d:.3e}'  # 2 steps of lr 1e-3; grads differ by fp32 atomics order
+            assert torch.equal(a, b), f'{k}: sharded step differs from the unsharded one ({(a - b).abs().max().item():.3e})'
         for (k, a), (_, b) in zip(ema.named_parameters(), ref_ema.named_parameters()):
-            assert (a - b).abs().max().item() <= 1e-4, f'EMA {k} differs after sync_ema'
+            assert torch.equal(a, b), f'EMA {k} differs after sync_ema'
         assert sd['param_groups'][0]['step'] == rsd['param_groups'][0]['step'] == 2
         for i in rsd['state']:
-            assert torch.allclose(sd['state'][i]['exp_avg'], rsd['state'][i]['exp_avg'], rtol=5e-2, atol=1e-6), f'moment {i}'
+            assert torch.equal(sd['state'][i]['exp_avg'], rsd['state'][i]['exp_avg']), f'moment {i}'
+            assert torch.equal(sd['state'][i]['exp_avg_sq'], rsd['state'][i]['exp_avg_sq']), f'moment {i}'
         for arena in (net.engine().P, ema.engine().P):
             other = arena.detach().clone()
             dist.broadcast(other, src=0)

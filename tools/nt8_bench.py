@@ -4,8 +4,10 @@ For every (shape, epilogue) of an XL/2 encoder block + the decoder shapes: TFLOP
   full      : the product path (auto dispatch)
   no-epi    : main loop only (mdt_set_tuning nt8_skip_epilogue) -> what the epilogue costs per launch
   nf3       : 192-column tiles preferred (no spill, deeper look-ahead)   [only where N % 192 == 0 and N % 256 == 0]
-  stagger   : every other workgroup starts half a tile late (lock-step A/B)
   4-wave    : 128-row tiles, two workgroups per CU
+  240 CUs   : persistent grid capped at 240 workgroups (what DataParallel reserves for RCCL)
+  trickle   : TIMING EXPERIMENT (garbage results): the GATE_RES epilogue's bytes issued one 16-byte op per phase INSIDE
+              the K loop -- how much of the epilogue could hide under the MFMA work of the same CU
 Interleaved rounds, best-of time per variant."""
 import argparse
 import ctypes as C
@@ -42,9 +44,8 @@ def main():
         shapes += [((Md, 1536, 512), 'BF16', 'dec qkv'), ((Md, 512, 512), 'GATE_RES', 'dec proj'), ((Md, 2048, 512), 'GELU', 'dec fc1'),
                    ((Md, 512, 2048), 'GATE_RES', 'dec fc2'), ((Md, 2048, 512), 'DGELU', 'dec fc2 dgrad'), ((Md, 512, 2048), 'BF16', 'dec fc1 dgrad')]
     variants = [('full', {}), ('no-epi', {'nt8_skip_epilogue': 1}), ('nf3', {'nt8_nf3': 1}), ('4-wave', {'gemm_nt_variant': 3}),
-                ('4w+stagger', {'gemm_nt_variant': 3, 'nt8_stagger': 1}), ('128 CUs', {'nt8_max_cus': 128}),
-                ('128CU no-epi', {'nt8_max_cus': 128, 'nt8_skip_epilogue': 1})]
-    knobs = ['nt8_skip_epilogue', 'nt8_nf3', 'nt8_stagger', 'gemm_nt_variant', 'nt8_max_cus']
+                ('240 CUs', {'nt8_max_cus': 240}), ('trickle', {'nt8_trickle': 1})]
+    knobs = ['nt8_skip_epilogue', 'nt8_nf3', 'nt8_stagger', 'gemm_nt_variant', 'nt8_max_cus', 'nt8_trickle']
     print(f'{"shape / epilogue":40s} ' + ' '.join(f'{v[0]:>16s}' for v in variants) + '    (TFLOP/s | us)')
     for (m, n, k), name, tag in shapes:
         A = (torch.randn(m, k, device=dev) * 0.5).to(torch.bfloat16)
@@ -63,6 +64,8 @@ def main():
             for vname, kn in variants:
                 if vname == 'nf3' and not (n % 192 == 0 and n % 256 == 0):
                     continue
+                if vname == 'trickle' and not (name == 'GATE_RES' and n % 192 == 0):
+                    continue  # the overlap experiment exists for the 256 x 192 GATE_RES tiles only
                 for key in knobs:
                     L.mdt_set_tuning(key.encode(), kn.get(key, 0))
                 ops.gemm_nt(A, Wt, **kw)
