@@ -180,6 +180,13 @@ def _zero_worker(rank, world, port, q):
                     dist.broadcast(Gfull[bounds[r]:bounds[r + 1]], src=r)
             lo, hi = bounds[rank], bounds[rank + 1]
             assert torch.equal(Gfull[lo:hi], G[lo:hi])
+            if s == 0:  # sanity of the reduce-to-owner gradient itself: the full-batch gradient within atomics noise
+                ref2 = build()
+                run(ref2, 0, slice(0, B)).mean().backward()
+                gf = ref2.engine().G
+                relg = ((Gfull - gf).norm() / gf.norm()).item()
+                assert relg <= 5e-3, f'reduce-to-owner gradient differs from the full-batch gradient ({relg:.3e})'
+                del ref2, gf
             ropt.zero_grad(set_to_none=True)
             ref._prepare_grad_arena()
             ref.engine().G.copy_(Gfull)
@@ -187,12 +194,6 @@ def _zero_worker(rank, world, port, q):
             M.update_ema(ema, net, 0.99)
             ropt.step()
             M.update_ema(ref_ema, ref, 0.99)
-        # sanity of the reduce-to-owner gradient itself: equals the full-batch gradient within atomics noise
-        ref2 = build()
-        run(ref2, 1, slice(0, B)).mean().backward()
-        gf = ref2.engine().G
-        relg = ((Gfull - gf).norm() / gf.norm()).item()
-        assert relg <= 5e-3, f'reduce-to-owner gradient differs from the full-batch gradient ({relg:.3e})'
         opt.sync_ema()
         sd = opt.state_dict()
         rsd = ropt.state_dict()
@@ -234,5 +235,8 @@ def test_zero1_matches_unsharded():
     res = [q.get(timeout=500) for _ in procs]
     for p in procs:
         p.join(60)
-    assert all(r[1] == 'ok' for r in res), res
-    print('ZeRO-1 vs unsharded: worst parameter difference after 2 steps', max(r[2] for r in res))
+    for r in res:
+        if r[1] != 'ok':
+            print(r[1])
+    assert all(r[1] == 'ok' for r in res), [r[1][-600:] for r in res]
+    print('ZeRO-1: reduce-to-owner gradient vs full-batch gradient, rel L2', max(r[2] for r in res))
