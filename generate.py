@@ -8,8 +8,9 @@ hipGraph-captured EDM Heun sampler with classifier-free guidance, latents writte
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 generate.py ...   # seeds sharded by rank
 
 Seeds are split over the ranks exactly as sample.py:233-235 does (no exchange step: replicas only).
-The VAE decode + PNG step of the reference (sample.py:273-296) is out of scope (weights are not
-available offline): the fp64 latents `z` are the product."""
+`--pretrained_path autoencoder_kl.pth` adds the reference's decode step (sample.py:248,273-296): the latents go through
+maskdit_amd.autoencoder (HIP) and are written as uint8 images (`.png` when PIL is importable, else `.npy`); without it the
+fp64 latents `z` are the product (the published VAE weights are not available offline)."""
 from __future__ import annotations
 
 import argparse
@@ -53,6 +54,7 @@ def main(argv=None):
     ap.add_argument('--cfg_scale', type=float, default=None)
     ap.add_argument('--class_idx', type=int, default=None)
     ap.add_argument('--subdirs', action='store_true', help='one sub-directory per 1000 seeds (sample.py:288)')
+    ap.add_argument('--pretrained_path', default=None, help='autoencoder_kl.pth: decode the latents to images (sample.py:248)')
     args = ap.parse_args(argv)
     cfg = load_config(args.config)
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -66,6 +68,10 @@ def main(argv=None):
                                        pad_cls_token=mc.pad_cls_token).to(dev).eval()
     if args.ckpt_path:
         load_weights(net, args.ckpt_path)
+    vae = None
+    if args.pretrained_path:
+        from maskdit_amd import autoencoder
+        vae = autoencoder.get_model(args.pretrained_path).to(dev)
     os.makedirs(args.outdir, exist_ok=True)
     t0, n = time.time(), 0
     for seeds in M.seed_batches(args.seeds, args.max_batch_size, rank, world):
@@ -78,10 +84,20 @@ def main(argv=None):
             labels[:, :] = 0
             labels[:, args.class_idx] = 1
         z = M.edm_sampler(net, latents, labels, cfg_scale=args.cfg_scale, randn_like=rnd.randn_like, num_steps=args.num_steps)
-        for s, zi in zip(seeds, z.cpu().numpy()):
+        images = None
+        if vae is not None:  # sample.py:282-286: decode, [-1, 1] -> uint8 HWC
+            images = vae.decode(z.float()).add_(1).mul_(127.5).clamp_(0, 255).to(torch.uint8).permute(0, 2, 3, 1).cpu().numpy()
+        for j, (s, zi) in enumerate(zip(seeds, z.cpu().numpy())):
             d = os.path.join(args.outdir, f'{s - s % 1000:06d}') if args.subdirs else args.outdir
             os.makedirs(d, exist_ok=True)
-            np.save(os.path.join(d, f'{s:06d}.npy'), zi)
+            if images is None:
+                np.save(os.path.join(d, f'{s:06d}.npy'), zi)
+                continue
+            try:
+                import PIL.Image
+                PIL.Image.fromarray(images[j], 'RGB').save(os.path.join(d, f'{s:06d}.png'))
+            except ImportError:
+                np.save(os.path.join(d, f'{s:06d}.npy'), images[j])
         n += len(seeds)
     torch.cuda.synchronize()
     print(f'[rank {rank}/{world}] {n} latents, {args.num_steps} steps, cfg={args.cfg_scale}: {n / (time.time() - t0):.2f} samples/s', flush=True)

@@ -235,6 +235,29 @@ int mdt_sampler_advance(int32_t* step_idx, mdt_stream_t stream);
 /* classifier-free guidance combine on F = [cond; uncond] (models/maskdit.py:580-583), n = B*chw */
 int mdt_cfg_combine(const float* F, float cfg_scale, float* out, long n, mdt_stream_t stream);
 
+/* ---------------------------------------------------------------- VAE decoder glue ------ */
+
+/* The KL-autoencoder decoder that follows the sampler (autoencoder.py:306-410 Decoder, :449-453 decode; call sites
+ * sample.py:248,273-284).  Activations are NHWC fp32 [B*H*W, C]; every convolution is one mdt_gemm_nt on an im2col
+ * matrix written by mdt_gn_im2col with the GroupNorm / swish / up-sampling in front of it already applied. */
+/* sums[b, g, 0..1] = (sum, sum of squares) over the H*W*(C/groups) elements of group g (autoencoder.py:35-36
+ * Normalize = GroupNorm(32, eps 1e-6, affine)); cleared on the stream by the call. */
+int mdt_gn_stats(const float* x, float* sums, int B, int HW, int C, int groups, mdt_stream_t stream);
+/* col[(b, yo, xo), (ky, kx, c)] = swish?(gamma * (x - mean) * rstd + beta) at input pixel ((yo+ky-1) >> up, (xo+kx-1) >> up),
+ * zero outside the (up-sampled) image and in the padding columns [k*k*C, Kp): ResnetBlock.norm1/2 + nonlinearity +
+ * conv padding (autoencoder.py:118-129), Upsample.interpolate(nearest, 2x) (:49), AttnBlock.norm (:176).  sums = NULL:
+ * no normalisation (conv_in, the up-sampling convolutions, nin_shortcut). */
+int mdt_gn_im2col(const float* x, const float* sums, const float* gamma, const float* beta, mdt_bf16* col, int B, int H,
+                  int W, int C, int groups, int ksize, int upsample, int swish, int Kp, mdt_stream_t stream);
+/* out[r, :] = softmax(in[r, :] * scale) as bf16 (AttnBlock, autoencoder.py:188-190) */
+int mdt_softmax_rows(const float* in, mdt_bf16* out, int R, int n, float scale, mdt_stream_t stream);
+/* y[b, p, :] = W (z[b, :, p] / scale_factor) + bias: FrozenAutoencoderKL.decode's rescale + post_quant_conv
+ * (autoencoder.py:449-451), NCHW fp32 in, NHWC fp32 out (4 channels) */
+int mdt_vae_prologue(const float* z, const float* w, const float* bias, float* y, int B, int HW, float scale_factor,
+                     mdt_stream_t stream);
+/* img[b, c, p] = in[(b, p), c], c < Cout: the decoder output back in the reference's NCHW layout */
+int mdt_vae_epilogue(const float* in, int ld, float* img, int B, int HW, int Cout, mdt_stream_t stream);
+
 /* hipGraph helpers (stream capture of a sequence of the calls above). */
 int mdt_graph_begin(mdt_stream_t stream);
 int mdt_graph_end(mdt_stream_t stream, void** graph_exec_out);

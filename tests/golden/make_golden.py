@@ -199,7 +199,36 @@ def gen_param_order():
     print('param_order.json written')
 
 
+def gen_vae():
+    """Decode path of the reference's autoencoder.py (Decoder + post_quant_conv modules, ddconfig of get_model) loaded
+    with the oracle's synthetic weights; the published autoencoder_kl.pth is not available offline.  Stores the image of
+    ONE latent in full (fp16, 393 K values) + checksums of a second one."""
+    import autoencoder as ref_ae  # noqa  (reference)
+    from oracle import vae_oracle as VO
+    ddconfig = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4],
+                    num_res_blocks=2, attn_resolutions=[], dropout=0.0)
+    dec = ref_ae.Decoder(**ddconfig)
+    pq = torch.nn.Conv2d(4, 4, 1)
+    P = VO.init_vae_params(seed=11)
+    ref_keys = {'decoder.' + k: tuple(v.shape) for k, v in dec.state_dict().items()}
+    ref_keys.update({'post_quant_conv.' + k: tuple(v.shape) for k, v in pq.state_dict().items()})
+    assert ref_keys == VO.vae_param_shapes(), 'oracle key / shape table differs from the reference modules'
+    dec.load_state_dict({k[len('decoder.'):]: v for k, v in P.items() if k.startswith('decoder.')}, strict=True)
+    pq.load_state_dict({k[len('post_quant_conv.'):]: v for k, v in P.items() if k.startswith('post_quant_conv.')}, strict=True)
+    dec.eval()
+    g = torch.Generator().manual_seed(12)
+    z = 0.5 * torch.randn(2, 4, 32, 32, generator=g)
+    with torch.no_grad():
+        img = dec(pq(z / 0.18215))  # FrozenAutoencoderKL.decode, autoencoder.py:449-453
+    c = checks(img[1])
+    np.savez_compressed(os.path.join(HERE, 'vae_decode.npz'), seed=np.int64(11), z=z.numpy(), img0=img[0].numpy().astype(np.float16),
+                        img0_absmax=np.float64(img[0].abs().max().item()), img1_sums=c[0], img1_samples=c[1],
+                        order=np.array(list(dec.state_dict().keys())))
+    print('vae_decode.npz written; image std', img.std().item(), 'absmax', img.abs().max().item())
+
+
 JOBS = {
+    'vae': gen_vae,
     'param_order': gen_param_order,
     'mask': gen_mask,
     'moments': gen_moments,

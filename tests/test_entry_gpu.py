@@ -143,3 +143,24 @@ def test_generate_writes_per_seed_latents(tmp_path):
     G.main(['--config', cfg, '--seeds', '7', '--num_steps', '4', '--cfg_scale', '1.5', '--outdir', os.path.join(tmp, 't')])
     b = np.load(os.path.join(tmp, 't', '000007.npy'))
     assert np.abs(a - b).max() <= 2e-2 * np.abs(a).max()  # bf16 network: batch-size-dependent GEMM tiling only
+
+
+def test_generate_with_vae_decode_writes_images(tmp_path):
+    """generate.py --pretrained_path: sampler latents -> maskdit_amd.autoencoder -> uint8 images (sample.py:248,273-296),
+    with a synthetic-weight checkpoint in the reference's layout (encoder.* keys included, as in autoencoder_kl.pth)."""
+    import generate as G
+    from oracle import vae_oracle as VO
+    tmp = str(tmp_path)
+    cfg = _cfg(tmp)
+    sd = VO.init_vae_params(seed=11)
+    sd['encoder.conv_in.weight'] = torch.zeros(128, 3, 3, 3)
+    ck = os.path.join(tmp, 'autoencoder_kl.pth')
+    torch.save(sd, ck)
+    n = G.main(['--config', cfg, '--seeds', '0-2', '--num_steps', '3', '--cfg_scale', '1.5', '--outdir', os.path.join(tmp, 'img'),
+                '--pretrained_path', ck])
+    assert n == 3
+    files = sorted(os.listdir(os.path.join(tmp, 'img')))
+    assert files == ['000000.png', '000001.png', '000002.png']
+    import PIL.Image
+    im = np.asarray(PIL.Image.open(os.path.join(tmp, 'img', files[1])))
+    assert im.shape == (256, 256, 3) and im.dtype == np.uint8 and im.std() > 1.0

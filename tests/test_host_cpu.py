@@ -266,3 +266,30 @@ def test_reference_yaml_configs_parse_and_are_supported():
                     get_mask_ratio_fn(name, mc.mask_ratio, mc.get('mask_ratio_min', 0))
             else:
                 get_mask_ratio_fn(name, mc.mask_ratio, mc.get('mask_ratio_min', 0))(0.5)
+
+
+def test_vae_decoder_surface_cpu(golden_dir):
+    """Decode-side drop-in of autoencoder.py: reference state-dict keys / shapes in the reference's module order, the full
+    checkpoint (with encoder.* / quant_conv.* entries) loads, missing decode keys are an error, no CPU compute path."""
+    import maskdit_amd as M
+    from maskdit_amd import autoencoder as AE
+    from oracle import vae_oracle as VO
+    g = np.load(os.path.join(golden_dir, 'vae_decode.npz'))
+    ref_order = ['post_quant_conv.weight', 'post_quant_conv.bias'] + ['decoder.' + str(k) for k in g['order']]
+    table = AE.decoder_param_table()
+    assert [n for n, _ in table] == ref_order  # `parameters()` order of the reference Decoder (self.up.insert(0, ...))
+    assert {n: tuple(s) for n, s in table} == VO.vae_param_shapes()
+    vae = AE.get_model(None)
+    P = VO.init_vae_params(seed=3)
+    full = dict(P)
+    full['encoder.conv_in.weight'] = torch.zeros(128, 3, 3, 3)   # present in autoencoder_kl.pth, not on the decode path
+    full['quant_conv.weight'] = torch.zeros(8, 8, 1, 1)
+    vae.load_state_dict(full)
+    assert torch.equal(vae.state_dict()['decoder.mid.attn_1.q.weight'], P['decoder.mid.attn_1.q.weight'])
+    broken = {k: v for k, v in P.items() if k != 'decoder.conv_out.bias'}
+    with pytest.raises(RuntimeError):
+        vae.load_state_dict(broken)
+    with pytest.raises(M.MaskDiTLibError):
+        vae.decode(torch.zeros(1, 4, 32, 32))
+    with pytest.raises(NotImplementedError):
+        vae.encode(torch.zeros(1, 3, 256, 256))

@@ -148,3 +148,21 @@ def test_xl2_sampler_matches_reference(golden_dir):
     z = O.edm_sampler(P, cfg, torch.from_numpy(g['latents']), labels, cfg_scale=float(g['cfg_scale']),
                       num_steps=int(g['num_steps']))
     np.testing.assert_allclose(z.numpy(), g['z'], rtol=1e-4, atol=1e-4)
+
+
+def test_vae_decode_oracle_matches_reference(golden_dir):
+    """the decode path of the reference's autoencoder.py (its own Decoder / post_quant_conv modules with the
+    oracle's synthetic weights; tests/golden/make_golden.py: gen_vae) against oracle/vae_oracle.py."""
+    from oracle import vae_oracle as VO
+    from tests.golden.make_golden_idx import sample_idx
+    g = _load(golden_dir, 'vae_decode.npz')
+    P = VO.init_vae_params(seed=int(g['seed']))
+    with torch.no_grad():
+        img = VO.vae_decode(P, torch.from_numpy(g['z']))
+    assert img.shape == (2, 3, 256, 256)
+    ref0 = g['img0'].astype(np.float32)  # stored as fp16: 1e-3 relative quantisation
+    np.testing.assert_allclose(img[0].numpy(), ref0, rtol=2e-3, atol=2e-3 * float(g['img0_absmax']))
+    got = _sums(img[1])
+    np.testing.assert_allclose(got, g['img1_sums'], rtol=1e-4)
+    idx = sample_idx(img[1].numel())
+    np.testing.assert_allclose(img[1].double().flatten()[idx].numpy(), g['img1_samples'], rtol=1e-3, atol=1e-4)

@@ -1,0 +1,104 @@
+"""VAE decode after the sampler on the GPU: the glue kernels against torch fp32, the whole decoder
+against the reference-generated fixture (tests/golden/vae_decode.npz) and the oracle.  Tolerances: fp32 kernels 1e-5;
+bf16-GEMM quantities stated at the test."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+if torch.cuda.is_available():
+    from maskdit_amd import autoencoder as AE
+    from maskdit_amd import ops
+    from maskdit_amd._lib import call
+    from oracle import vae_oracle as VO
+
+
+def _st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _relmax(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+@pytest.mark.parametrize('B,H,C,ks,up,norm,swish', [(2, 8, 128, 3, 0, True, True), (3, 4, 512, 3, 1, False, False),
+                                                    (2, 8, 256, 1, 0, True, False), (1, 16, 128, 3, 1, True, True)])
+def test_gn_stats_and_im2col(B, H, C, ks, up, norm, swish):
+    torch.manual_seed(1)
+    x = (torch.randn(B, H, H, C, device=DEV) * 1.7 + 0.3).contiguous()  # NHWC
+    gamma, beta = torch.randn(C, device=DEV) * 0.3 + 1, torch.randn(C, device=DEV) * 0.2
+    sums = torch.full((B, 32, 2), 9.0, device=DEV)  # stale contents must be cleared by the call
+    call('mdt_gn_stats', x.data_ptr(), sums.data_ptr(), B, H * H, C, 32, _st())
+    xg = x.view(B, H * H, 32, C // 32)
+    ref_s = torch.stack([xg.sum((1, 3)), (xg * xg).sum((1, 3))], -1)
+    assert _relmax(sums, ref_s) < 1e-5
+    Kp = ks * ks * C
+    Ho = H << up
+    col = torch.empty(B * Ho * Ho, Kp, device=DEV, dtype=torch.bfloat16)
+    call('mdt_gn_im2col', x.data_ptr(), sums.data_ptr() if norm else None, gamma.data_ptr() if norm else None,
+         beta.data_ptr() if norm else None, col.data_ptr(), B, H, H, C, 32, ks, up, int(swish), Kp, _st())
+    t = x.permute(0, 3, 1, 2)  # NCHW
+    if norm:
+        t = F.group_norm(t, 32, gamma, beta, eps=1e-6)
+    if swish:
+        t = t * torch.sigmoid(t)
+    if up:
+        t = F.interpolate(t, scale_factor=2.0, mode='nearest')
+    cols = F.unfold(t, ks, padding=ks // 2)                                   # [B, C*ks*ks, Ho*Ho], channel-major
+    cols = cols.view(B, C, ks * ks, Ho * Ho).permute(0, 3, 2, 1).reshape(B * Ho * Ho, Kp)  # (tap, channel) order
+    assert _relmax(col.float(), cols) < 1e-2  # bf16 rounding of the stored operand
+
+
+def test_softmax_rows_and_vae_io_kernels():
+    torch.manual_seed(2)
+    s = torch.randn(96, 1024, device=DEV) * 20
+    out = torch.empty(96, 1024, device=DEV, dtype=torch.bfloat16)
+    call('mdt_softmax_rows', s.data_ptr(), out.data_ptr(), 96, 1024, 0.0442, _st())
+    ref = torch.softmax(s * 0.0442, -1)
+    assert _relmax(out.float(), ref) < 1e-2 and abs(out.float().sum(-1) - 1).max().item() < 2e-2
+    z = torch.randn(3, 4, 8, 8, device=DEV)
+    w, b = torch.randn(4, 4, 1, 1, device=DEV), torch.randn(4, device=DEV)
+    y = torch.empty(3 * 64, 4, device=DEV)
+    call('mdt_vae_prologue', z.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), 3, 64, 0.18215, _st())
+    ref = F.conv2d(z / 0.18215, w, b).permute(0, 2, 3, 1).reshape(3 * 64, 4)
+    assert _relmax(y, ref) < 1e-5
+    src = torch.randn(2 * 16, 128, device=DEV)
+    img = torch.empty(2, 3, 4, 4, device=DEV)
+    call('mdt_vae_epilogue', src.data_ptr(), 128, img.data_ptr(), 2, 16, 3, _st())
+    assert torch.equal(img, src[:, :3].reshape(2, 16, 3).permute(0, 2, 1).reshape(2, 3, 4, 4))
+
+
+def test_vae_decode_vs_reference_fixture(golden_dir):
+    """The whole decode path (32x32x4 latent -> 256x256x3 image, ~0.62 TFLOP per image) against the output of the
+    reference's own modules: bf16 operands / fp32 accumulation through 33 convolutions + the attention block versus
+    the reference's fp32 -- the test measures and bounds the difference (images are quantised to 1/255 = 0.4 % of their
+    [-1, 1] range afterwards, sample.py:286)."""
+    g = np.load(os.path.join(golden_dir, 'vae_decode.npz'))
+    P = VO.init_vae_params(seed=int(g['seed']))
+    vae = AE.get_model(None)
+    vae.load_state_dict(P)
+    vae = vae.to(DEV)
+    z = torch.from_numpy(g['z']).to(DEV)
+    img = vae.decode(z)
+    assert img.shape == (2, 3, 256, 256) and img.dtype == torch.float32 and bool(torch.isfinite(img).all())
+    ref0 = torch.from_numpy(g['img0'].astype(np.float32))
+    e0 = _relmax(img[0], ref0)
+    with torch.no_grad():
+        ref = VO.vae_decode(P, torch.from_numpy(g['z']))
+    e = _relmax(img, ref)
+    rms = ((img.cpu() - ref).norm() / ref.norm()).item()
+    print(f'VAE decode vs reference fixture (image 0): {e0:.3e} of max; vs oracle (both): {e:.3e} of max, {rms:.3e} rel L2')
+    assert e0 <= 3e-2 and e <= 3e-2 and rms <= 2e-2
+    # batch invariance + workspace reuse: a second call with one latent gives the same image
+    one = vae.decode(z[1:2])
+    assert _relmax(one[0], img[1]) <= 2e-3
+    # 64x64 latents (ImageNet-512): runs, finite, right shape
+    big = vae.decode(torch.randn(1, 4, 64, 64, device=DEV) * 0.5)
+    assert big.shape == (1, 3, 512, 512) and bool(torch.isfinite(big).all())
