@@ -442,6 +442,30 @@ def main():
             sampler = {'metric': f'EDM samples/sec {args.model} {args.sampler_steps}-step Heun cfg=1.5 bs={sb}', 'value': round(sb / te, 3),
                        'unit': 'samples/s', 'seconds': round(te, 3), 'net_evals': evals, 'finite': ok, 'hipgraph': True,
                        'model_tflops_per_s': round(sb * evals * 2 * 251.6e9 / te / 1e12, 1) if (args.model, R) == ('DiT-XL/2', 32) else None}
+            # the step that follows the sampler in generate.py (sample.py:248,273-284): VAE decode of the latents
+            # (random-init decoder of the reference architecture; ~0.62 TFLOP per 256^2 image)
+            try:
+                from maskdit_amd import autoencoder
+                vae = autoencoder.get_model(None)
+                with torch.no_grad():
+                    for _, p in vae.named_weights():
+                        if p.dim() == 4:
+                            p.normal_(std=(1.6 / (p.shape[1] * p.shape[2] * p.shape[3])) ** 0.5)
+                        elif p.dim() == 1:
+                            p.normal_(std=0.1).add_(1.0 if p.shape[0] >= 128 else 0.0)
+                vae = vae.to(dev)
+                zf = z.float()
+                vae.decode(zf)  # warm-up (packs the weights, sizes the workspace)
+                torch.cuda.synchronize()
+                tv = time.perf_counter()
+                img = vae.decode(zf)
+                torch.cuda.synchronize()
+                tv = time.perf_counter() - tv
+                sampler['vae_decode'] = {'seconds': round(tv, 4), 'images_per_s': round(sb / tv, 1), 'finite': bool(torch.isfinite(img).all()),
+                                         'samples_per_s_incl_decode': round(sb / (te + tv), 3)}
+                vae.release_workspace()
+            except Exception as e:  # noqa: BLE001
+                sampler['vae_decode'] = {'error': repr(e)}
         except Exception as e:
             sampler = {'value': None, 'error': repr(e)}
 
