@@ -96,7 +96,21 @@ __global__ __launch_bounds__(256) void patch_embed_bwd_kernel(const float* __res
     __syncthreads();
     if (d < D) {
       const int nt = (int)min((long)64, nrows - row0);
-      for (int t = 0; t < nt; ++t) {
+      // 8 independent 4-byte loads in flight per lane (the one-load-per-iteration form ran at 0.2 TB/s: every
+      // iteration waited for its own HBM round trip)
+      int t = 0;
+      for (; t + 8 <= nt; t += 8) {
+        float g[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) g[u] = dout[(row0 + t + u) * D + d];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          ab += g[u];
+#pragma unroll
+          for (int k = 0; k < 16; ++k) acc[k] += g[u] * pv[t + u][k];
+        }
+      }
+      for (; t < nt; ++t) {
         float g = dout[(row0 + t) * D + d];
         ab += g;
 #pragma unroll

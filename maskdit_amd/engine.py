@@ -46,7 +46,7 @@ LIVE_ENGINES: 'weakref.WeakSet' = weakref.WeakSet()  # lets the optimizer map a 
 # mdt_ln_modulate_bwd_gate (LayerNorm backward + the following residual-gate backward in one pass) saves 4 of
 # 22 B/element but needs 214 VGPRs (2 waves/SIMD): measured 215 us vs 111 + 46 us for the two separate
 # kernels on XL/2, so the plans use the separate kernels.  Flip to re-measure after a register diet.
-FUSE_LN_GATE = False
+FUSE_LN_GATE = os.environ.get('MDT_FUSE_LN_GATE', '0') == '1'  # A/B switch; round 2 rebuilt the kernel on LDS accumulators
 ADA_GROUP = 7  # encoder blocks per adaLN weight-gradient group (XL/2: 4 groups of 7 + the decoder-side group)
 FUSE_COLSUM = os.environ.get('MDT_FUSE_COLSUM', '1') != '0'  # fc1 bias gradient out of the DGELU epilogue (A/B switch)
 

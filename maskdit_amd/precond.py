@@ -429,4 +429,14 @@ def _run_cfg(net: EDMPrecond, x, sigma, labels, cfg_scale: float):
 
 
 Precond_models = {'edm': EDMPrecond}
-DiT_models = {name: name for name in MODEL_CONFIGS}  # model_type strings accepted by EDMPrecond
+
+
+def _dit_constructor(model_type):
+    """models/maskdit.py:649-715 `DiT_XL_2(**kwargs)` ...: constructor registry of the bare DiT parameter containers."""
+    def build(input_size=32, in_channels=4, num_classes=1000, use_decoder=True, mae_loss_coef=0.1, **unused):
+        return DiT(make_spec(model_type, input_size, in_channels, num_classes, use_decoder, mae_loss_coef))
+    build.__name__ = model_type.replace('-', '_').replace('/', '_')
+    return build
+
+
+DiT_models = {name: _dit_constructor(name) for name in MODEL_CONFIGS}  # models/maskdit.py:718-724
