@@ -88,12 +88,6 @@ template <int N> __device__ __forceinline__ void wait_vm_lgkm() {
   asm volatile("" ::: "memory");
 }
 
-// identity that hipcc cannot see through: keeps (uniform base) + (32-bit lane offset) address expressions in the
-// saddr + voffset form instead of one 64-bit vector address per access
-__device__ __forceinline__ unsigned opaque(unsigned v) {
-  asm volatile("" : "+v"(v));
-  return v;
-}
 __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   bf16x2 t;
   t[0] = f2bf(lo);

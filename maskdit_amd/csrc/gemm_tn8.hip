@@ -1,14 +1,14 @@
 // gemm_tn8: the large-problem weight-gradient GEMM  out[x, y] += sum_m X[m, x] * Y[m, y]
 // (contraction over ROWS; X, Y row-major bf16; fp32 atomic accumulation, split over m).
 //
-// 256 (x) x 128 (y) output tile per 512-thread workgroup: 8 waves as 4(x) x 2(y), wave tile
-// 64 x 64 = 4 x 4 MFMA 16x16x32 accumulators.  The contraction index is the slow (row) index of
+// 256 (x) x 128 or 192 (y) output tile per 512-thread workgroup: 8 waves as 4(x) x 2(y), wave tile
+// 64 x 64 or 64 x 96 = 4 x 4 / 4 x 6 MFMA 16x16x32 accumulators.  The contraction index is the slow (row) index of
 // both operands, so tiles are kept in LDS exactly as they lie in memory ([m][n], 256-byte rows per
 // 128-column half) and MFMA operands are fetched with the gfx950 LDS transpose read
 // (ds_read_b64_tr_b16, two per fragment).  Pipeline: a ring of NSLOT slots of 32 contraction rows
 // (one MFMA k-step); phase g = [tr-read the fragments of slot g+1 into the alternate register set]
 // [LDS-DMA refill of the slot that was read during phase g-1 with rows of phase g+NSLOT]
-// [16 MFMAs] [s_waitcnt vmcnt((NSLOT-2)*3) lgkmcnt(0)] [s_barrier]: every load has NSLOT-2 phases
+// [16 / 24 MFMAs] [s_waitcnt vmcnt((NSLOT-2) * loads per slot) lgkmcnt(0)] [s_barrier]: every load has NSLOT-2 phases
 // to land and vmcnt(0) only appears in the last ring pass.  Same swizzle as the 128x128 kernel
 // (gemm.hip: tn_swz) through the DMA source address.
 //
@@ -18,15 +18,30 @@
 // the 256-wide role to whichever operand divides by 256.
 #include "gemm_common.h"
 
-#define TN8_NSLOT 6
-#define TN8_SLOT_BYTES 24576  // X half0 8K | X half1 8K | Y 8K   (32 rows x 256 B each)
+// Two tile shapes (template YF = 16-column Y fragments per wave):
+//   YF = 4: 256 x 128, ring of 6 slots (24 KiB each).  16 MFMAs per 16 transpose reads per wave and phase: the LDS
+//           port is busy 100 % of the MFMA time and a CU pulls 47 B/clk from L2 -- the round-1 shape, kept for widths
+//           that only divide by 128 (the 512-wide decoder).
+//   YF = 6: 256 x 192, ring of 5 slots (28 KiB each), wave tile 64 x 96: 24 MFMAs per 20 transpose reads (LDS 83 %),
+//           36 B/clk/CU from L2.  Every XL/2 encoder weight gradient has a 1152-wide side = 6 x 192.
+//           The extra 64 columns of Y live in a second LDS piece with 128-byte rows (own swizzle); waves 0-3 move it,
+//           so their vmcnt counts carry 4 loads per slot and those of waves 4-7 carry 3.
+template <int YF> struct TN8Cfg {
+  static constexpr int NSLOT = YF == 6 ? 5 : 6;
+  static constexpr int SLOT_BYTES = YF == 6 ? 28672 : 24576;  // X half0 8K | X half1 8K | Y[0,128) 8K | Y[128,192) 4K
+  static constexpr int TY = 32 * YF;
+  static constexpr int UNROLL = YF == 6 ? 10 : 6;  // lcm(ring slots, 2 register sets)
+};
 
 __device__ __forceinline__ int tn8_swz(int r) { return ((r & 3) | (((r >> 3) & 1) << 2)) << 1; }
+// 128-byte-row piece: 4 units of 32 B per row, two rows per 256-byte bank line.  The 8 rows one 32-lane half of a
+// transpose read touches (8g + j, g in a pair, j = 0..3) must land on 8 distinct (row & 1, unit) positions.
+__device__ __forceinline__ int tn8_swz2(int r) { return (((r >> 1) & 1) | (((r >> 3) & 1) << 1)) << 1; }
 
 struct TN8Params {
   const bf16* X; int ldx;
   const bf16* Y; int ldy;
-  int NX, NY;          // widths (NY % 128 == 0; NX % 128 == 0)
+  int NX, NY;          // widths (NY % tile width == 0; NX % 128 == 0)
   float* C; int ldc;
   int swap;            // 0: C[x*ldc + y]   1: C[y*ldc + x]
   int slots_total;     // contraction rows / 32
@@ -47,6 +62,7 @@ template <int OFF> __device__ __forceinline__ bf16x4 tn8_tr_read(unsigned addr) 
 }
 
 template <int N> __device__ __forceinline__ void tn8_wait() {
+  static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
   asm volatile("" ::: "memory");
@@ -54,136 +70,183 @@ template <int N> __device__ __forceinline__ void tn8_wait() {
 
 // SWAP = false: out tile rows = x (C[x, y]);  SWAP = true: the MFMA operands trade places so that the
 // accumulator tile is [y rows][x cols] and the atomics to C[y, x] stay lane-contiguous.
-template <bool SWAP>
+template <bool SWAP, int YF>
 __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TN8Params p) {
-  __shared__ __attribute__((aligned(16))) char smem[TN8_NSLOT * TN8_SLOT_BYTES];
+  using Cfg = TN8Cfg<YF>;
+  constexpr int NSLOT = Cfg::NSLOT, SLOT_BYTES = Cfg::SLOT_BYTES;
+  constexpr int NSET = (NSLOT + 2) / 3;
+  static_assert(2 * SLOT_BYTES + 1024 < 65536, "three slots per address set");
+  __shared__ __attribute__((aligned(16))) char smem[NSLOT * SLOT_BYTES];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wx = wave >> 1, wy = wave & 1;
+  const bool mover2 = YF == 6 && wave < 4;  // this wave also moves the 64-column piece of Y
 
   const int tiles = p.tiles_x * p.tiles_y;
   const int sid = xcd_remap(blockIdx.x, gridDim.x);
   const int split = sid / tiles;
   int tx, ty;
   tile_coords(sid - split * tiles, p.tiles_x, p.tiles_y, tx, ty);
-  const int x0 = tx * 256, y0 = ty * 128;
+  const int x0 = tx * 256, y0 = ty * Cfg::TY;
   const int s_begin = split * p.slots_per_split;
-  const int S = min(p.slots_per_split, p.slots_total - s_begin);  // >= TN8_NSLOT (host guarantees)
+  const int S = min(p.slots_per_split, p.slots_total - s_begin);  // >= NSLOT (host guarantees)
   if (S <= 0) return;
 
-  // ---- LDS-DMA addressing: per slot a wave moves rows 4w..4w+3 of X half 0, X half 1 and Y.
+  // ---- LDS-DMA addressing: per slot a wave moves rows 4w..4w+3 of X half 0, X half 1 and Y[0,128);
+  // waves 0-3 also rows 8w..8w+7 of Y[128,192).
   const int lr = lane >> 4, cpos = lane & 15;
   const int rloc = 4 * wave + lr;  // slot-local row
   const int gch = cpos ^ tn8_swz(rloc);
-  const long row0 = (long)s_begin * 32 + rloc;
   const int xc0 = min(x0 + gch * 8, p.NX - 8), xc1 = min(x0 + 128 + gch * 8, p.NX - 8);  // clamp ragged tiles
-  const bf16* x_src0 = p.X + row0 * p.ldx + xc0;
-  const bf16* x_src1 = p.X + row0 * p.ldx + xc1;
-  const bf16* y_src = p.Y + row0 * p.ldy + y0 + gch * 8;
-  const long x_step = 32L * p.ldx, y_step = 32L * p.ldy;
+  const int rloc2 = 8 * (wave & 3) + (lane >> 3);
+  // wave-uniform 64-bit bases (scalar registers, advanced per slot with scalar arithmetic) + one 32-bit lane offset per
+  // stream: the LDS-DMA instructions take the saddr + voffset form (same idiom as gemm_nt8_impl.h)
+  const char* const xu = (const char*)(p.X + (long)s_begin * 32 * p.ldx);
+  const char* const yu = (const char*)(p.Y + (long)s_begin * 32 * p.ldy + y0);
+  const unsigned x_lo0 = (unsigned)(rloc * p.ldx + xc0) * 2u, x_lo1 = (unsigned)(rloc * p.ldx + xc1) * 2u;
+  const unsigned y_lo = (unsigned)(rloc * p.ldy + gch * 8) * 2u;
+  const unsigned y_lo2 = (unsigned)(rloc2 * p.ldy + 128 + (((lane & 7) ^ tn8_swz2(rloc2)) << 3)) * 2u;
+  const long x_step = 64L * p.ldx, y_step = 64L * p.ldy;  // bytes per slot
   char* const lds_w = smem + wave * 1024;
 
   auto issue = [&](int slot, int s) {  // fill ring slot `slot` with contraction rows of phase s
-    char* base = lds_w + slot * TN8_SLOT_BYTES;
-    glds16(x_src0 + s * x_step, base);
-    glds16(x_src1 + s * x_step, base + 8192);
-    glds16(y_src + s * y_step, base + 16384);
+    char* base = lds_w + slot * SLOT_BYTES;
+    glds16(xu + s * x_step + opaque(x_lo0), base);
+    glds16(xu + s * x_step + opaque(x_lo1), base + 8192);
+    glds16(yu + s * y_step + opaque(y_lo), base + 16384);
+    if (YF == 6 && mover2) glds16(yu + s * y_step + opaque(y_lo2), base + 24576);
   };
+  // wait until all but this wave's loads of the newest `SLOTS` ring slots have landed
+#define TN8_WAIT_SLOTS(SLOTS)                                     \
+  {                                                               \
+    if (YF == 6 && mover2) tn8_wait<4 * (SLOTS)>();               \
+    else tn8_wait<3 * (SLOTS)>();                                 \
+  }
+  // The two waves of a SIMD (w and w + 4) run half a phase apart: while waves 0-3 issue their transpose reads and
+  // LDS-DMA (half A), waves 4-7 issue MFMAs (half B), and vice versa -- in lock-step both would queue ~24 memory
+  // instructions in front of an idle matrix pipe every phase.  One workgroup barrier per half; waves 4-7 take one
+  // extra barrier before the loop, waves 0-3 one after it.  Consequence for the ring protocol: a slot read by waves
+  // 0-3 in their half A of phase ph+1 needs waves 4-7's portion published one half earlier, so the late group waits
+  // for one slot more (NSLOT-3 outstanding instead of NSLOT-2).
+  const bool late = wave >= 4;
+#define TN8_WAIT_PHASE()                                          \
+  {                                                               \
+    if (late) tn8_wait<3 * (NSLOT - 3)>();                        \
+    else TN8_WAIT_SLOTS(NSLOT - 2)                                \
+  }
+#define TN8_BARRIER()                                             \
+  {                                                               \
+    __builtin_amdgcn_s_barrier();                                 \
+    asm volatile("" ::: "memory");                                \
+    __builtin_amdgcn_sched_barrier(0);                            \
+  }
 
   // ---- transpose-read addressing (gemm.hip gemm_tn_kernel): the 16-lane group g reads slot rows
   // 8g + 4t + (0..3) x 16 columns; lane i16 supplies row (i16>>2), 8-byte piece (i16&3).
+  // Wave (wx, wy): X columns 64 wx + 16 i; Y columns 64 wy + 16 j (j < 4) and, YF = 6, 128 + 32 wy + 16 (j - 4).
   const int i16 = lane & 15, g = lane >> 4;
-  const int sw = tn8_swz(8 * g + (i16 >> 2));
-  const int row_off = (8 * g + (i16 >> 2)) * 256 + ((i16 & 1) << 3);
-  const int cx0 = (wx & 1) * 8 + ((i16 & 3) >> 1), cy0 = wy * 8 + ((i16 & 3) >> 1);  // + 2*frag
-  // LDS byte addresses per fragment, one set per PAIR of ring slots so that the remaining
-  // (slot & 1) * SLOT_BYTES + 1024 * t fits the 16-bit instruction offset
+  const int trow = 8 * g + (i16 >> 2);
+  const int sw = tn8_swz(trow), sw2 = tn8_swz2(trow);
+  const int row_off = trow * 256 + ((i16 & 1) << 3);
+  const int row_off2 = trow * 128 + ((i16 & 1) << 3);
+  const int q1 = (i16 & 3) >> 1;
+  const int cx0 = (wx & 1) * 8 + q1, cy0 = wy * 8 + q1;  // + 2*frag
+  // LDS byte addresses per fragment, one set per THREE ring slots so that the remaining
+  // (slot % 3) * SLOT_BYTES + row offset of t fits the 16-bit instruction offset
   const unsigned lds_base = (unsigned)(size_t)LDS_PTR(smem);
-  unsigned xa[TN8_NSLOT / 2][4], ya[TN8_NSLOT / 2][4];
+  unsigned xa[NSET][4], ya[NSET][YF];
 #pragma unroll
-  for (int pr = 0; pr < TN8_NSLOT / 2; ++pr)
+  for (int pr = 0; pr < NSET; ++pr) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      xa[pr][i] = lds_base + pr * 2 * TN8_SLOT_BYTES + (wx >> 1) * 8192 + row_off + (((cx0 + 2 * i) ^ sw) << 4);
-      ya[pr][i] = lds_base + pr * 2 * TN8_SLOT_BYTES + 16384 + row_off + (((cy0 + 2 * i) ^ sw) << 4);
+      xa[pr][i] = lds_base + pr * 3 * SLOT_BYTES + (wx >> 1) * 8192 + row_off + (((cx0 + 2 * i) ^ sw) << 4);
+      ya[pr][i] = lds_base + pr * 3 * SLOT_BYTES + 16384 + row_off + (((cy0 + 2 * i) ^ sw) << 4);
     }
+#pragma unroll
+    for (int j = 4; j < YF; ++j)
+      ya[pr][j] = lds_base + pr * 3 * SLOT_BYTES + 24576 + row_off2 + (((wy * 4 + 2 * (j - 4) + q1) ^ sw2) << 4);
+  }
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][YF];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  bf16x8 Xr[2][4], Yr[2][4];
+    for (int j = 0; j < YF; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 Xr[2][4], Yr[2][YF];
 
 #define TN8_LOAD(set, slot)                                                                             \
   {                                                                                                     \
-    constexpr int so = ((slot) & 1) * TN8_SLOT_BYTES;                                                   \
+    constexpr int so = ((slot) % 3) * SLOT_BYTES;                                                       \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
-      Xr[set][i] = cat4(tn8_tr_read<so>(xa[(slot) >> 1][i]), tn8_tr_read<so + 1024>(xa[(slot) >> 1][i])); \
-      Yr[set][i] = cat4(tn8_tr_read<so>(ya[(slot) >> 1][i]), tn8_tr_read<so + 1024>(ya[(slot) >> 1][i])); \
+      Xr[set][i] = cat4(tn8_tr_read<so>(xa[(slot) / 3][i]), tn8_tr_read<so + 1024>(xa[(slot) / 3][i])); \
+      Yr[set][i] = cat4(tn8_tr_read<so>(ya[(slot) / 3][i]), tn8_tr_read<so + 1024>(ya[(slot) / 3][i])); \
     }                                                                                                   \
+    _Pragma("unroll") for (int j = 4; j < YF; ++j)                                                      \
+      Yr[set][j] = cat4(tn8_tr_read<so>(ya[(slot) / 3][j]), tn8_tr_read<so + 512>(ya[(slot) / 3][j])); \
   }
 
-  // ---- prologue: fill the ring in steady-state order, wait for slot 0, load its fragments
+  // ---- prologue: fill the ring in steady-state order, wait for slots 0..2, load the fragments of slot 0
 #pragma unroll
-  for (int s = 0; s < TN8_NSLOT; ++s) issue(s, s);
-  tn8_wait<3 * (TN8_NSLOT - 1)>();
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
+  for (int s = 0; s < NSLOT; ++s) issue(s, s);
+  TN8_WAIT_SLOTS(NSLOT - 3)
+  TN8_BARRIER()
   TN8_LOAD(0, 0)
-  tn8_wait<3 * (TN8_NSLOT - 2)>();  // slot 1 landed as well (read during phase 0); LDS reads of slot 0 retired
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
+  tn8_wait<63>();  // lgkmcnt(0): every wave's reads of slot 0 retired before the early group refills it
+  TN8_BARRIER()
+  if (late) TN8_BARRIER()
 
   // one phase; K is a literal so that ring slot, register set and instruction offsets are static
 #define TN8_PHASE(K)                                                                                    \
-  {                                                                                                     \
+  if constexpr ((K) < Cfg::UNROLL) {                                                                    \
     const int ph = g0 + (K);                                                                            \
     if (ph < S) {                                                                                       \
-      /* (1) fragments of the next phase */                                                             \
-      if (ph + 1 < S) TN8_LOAD(((K) + 1) & 1, ((K) + 1) % TN8_NSLOT)                                    \
+      /* half A (1) fragments of the next phase */                                                      \
+      if (ph + 1 < S) TN8_LOAD(((K) + 1) & 1, ((K) + 1) % NSLOT)                                        \
       /* (2) slot K was read during the previous phase: refill it with the rows of phase ph+NSLOT */    \
-      if (ph + TN8_NSLOT < S) issue((K), ph + TN8_NSLOT);                                               \
-      /* (3) this phase's MFMAs */                                                                      \
+      if (ph + NSLOT < S) issue((K) % NSLOT, ph + NSLOT);                                               \
+      tn8_wait<63>(); /* lgkmcnt(0): the other group refills the slot just read in ITS next half A */   \
+      TN8_BARRIER()                                                                                     \
+      /* half B (3) this phase's MFMAs */                                                               \
       __builtin_amdgcn_s_setprio(1);                                                                    \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                     \
+      _Pragma("unroll") for (int j = 0; j < YF; ++j)                                                    \
         acc[i][j] = SWAP ? mfma16(Yr[(K) & 1][j], Xr[(K) & 1][i], acc[i][j])                            \
                          : mfma16(Xr[(K) & 1][i], Yr[(K) & 1][j], acc[i][j]);                           \
       __builtin_amdgcn_s_setprio(0);                                                                    \
-      /* (4) publish the slot that the next phase reads (data of phase ph+2) */                         \
-      if (ph + TN8_NSLOT + 1 <= S) tn8_wait<3 * (TN8_NSLOT - 2)>();                                     \
+      /* (4) publish this wave's share of the slot read two (early group) / three (late group) halves on */ \
+      if (ph + NSLOT + 1 <= S) TN8_WAIT_PHASE()                                                         \
       else tn8_wait<0>();                                                                               \
-      __builtin_amdgcn_s_barrier();                                                                     \
-      asm volatile("" ::: "memory");                                                                    \
-      __builtin_amdgcn_sched_barrier(0);                                                                \
+      TN8_BARRIER()                                                                                     \
     }                                                                                                   \
   }
-  static_assert(TN8_NSLOT == 6, "the ring pass below is written out for 6 slots");
-  for (int g0 = 0; g0 < S; g0 += TN8_NSLOT) {
+  for (int g0 = 0; g0 < S; g0 += Cfg::UNROLL) {
     TN8_PHASE(0) TN8_PHASE(1) TN8_PHASE(2) TN8_PHASE(3) TN8_PHASE(4) TN8_PHASE(5)
+    TN8_PHASE(6) TN8_PHASE(7) TN8_PHASE(8) TN8_PHASE(9)
   }
+  if (!late) TN8_BARRIER()
 #undef TN8_PHASE
 #undef TN8_LOAD
+#undef TN8_WAIT_SLOTS
+#undef TN8_WAIT_PHASE
+#undef TN8_BARRIER
 
   // ---- epilogue: fp32 atomics.  MFMA C layout: col = lane&15 (second operand's index), row =
   // 4*(lane>>4) + r (first operand's index); either way the 16 lanes of a group hit 64 contiguous bytes.
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < YF; ++j) {
+      const int yb = y0 + (j < 4 ? wy * 64 + j * 16 : 128 + wy * 32 + (j - 4) * 16);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (!SWAP) {
           const int x = x0 + wx * 64 + i * 16 + g * 4 + r;
-          const int y = y0 + wy * 64 + j * 16 + i16;
+          const int y = yb + i16;
           if (x < p.NX) atomic_add_f32(p.C + (long)x * p.ldc + y, acc[i][j][r]);
         } else {
           const int x = x0 + wx * 64 + i * 16 + i16;
-          const int y = y0 + wy * 64 + j * 16 + g * 4 + r;
+          const int y = yb + g * 4 + r;
           if (x < p.NX) atomic_add_f32(p.C + (long)y * p.ldc + x, acc[i][j][r]);
         }
       }
@@ -193,17 +256,30 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TN8Params p) {
 int launch_gemm_tn8(const bf16* A, int lda, const bf16* B, int ldb, int M, int N1, int N2, float* C, int ldc,
                     hipStream_t stream) {
   TN8Params p;
-  // give the 256-wide role to an operand whose width divides by 256 if there is one, else to the wider
-  const bool a_is_x = (N1 % 256 == 0) ? true : (N2 % 256 == 0) ? false : (N1 >= N2);
+  // Role assignment.  The 192-wide Y tile (YF = 6) wins whenever one width divides by 192: among the legal
+  // assignments take the one that wastes the fewest MFMAs on the ragged 256-wide X tile; otherwise the 256 x 128 shape
+  // with the 256-wide role on a width that divides by 256 if there is one.
+  auto x_waste = [](int nx) { return (double)(((nx + 255) / 256) * 256) / nx; };
+  const int knob = mdt_get_tuning_int(MDT_TUNE_TN8_WIDE);  // 1: never use the 256 x 192 shape (A/B runs)
+  int yf = 4;
+  bool a_is_x;
+  const bool b192 = knob != 1 && N2 % 192 == 0, a192 = knob != 1 && N1 % 192 == 0;
+  if (b192 || a192) {
+    yf = 6;
+    a_is_x = b192 && (!a192 || x_waste(N1) <= x_waste(N2));
+  } else {
+    a_is_x = (N1 % 256 == 0) ? true : (N2 % 256 == 0) ? false : (N1 >= N2);
+  }
   if (a_is_x) { p.X = A; p.ldx = lda; p.NX = N1; p.Y = B; p.ldy = ldb; p.NY = N2; p.swap = 0; }
   else { p.X = B; p.ldx = ldb; p.NX = N2; p.Y = A; p.ldy = lda; p.NY = N1; p.swap = 1; }
   p.C = C; p.ldc = ldc;
+  const int nslot = yf == 6 ? TN8Cfg<6>::NSLOT : TN8Cfg<4>::NSLOT;
   p.tiles_x = (p.NX + 255) / 256;
-  p.tiles_y = p.NY / 128;
+  p.tiles_y = p.NY / (32 * yf);
   p.slots_total = M / 32;
   const int tiles = p.tiles_x * p.tiles_y;
   // split the contraction: minimise (waves of 256 workgroups) x (slots per split + fixed per-block cost
-  // ~ prologue latency + 32K epilogue atomics, worth about 48 slots of MFMA work)
+  // ~ prologue latency + 32K-48K epilogue atomics, worth about 48 slots of MFMA work)
   int best = 1;
   double best_cost = 1e30;
   for (int sp = 1; sp <= 64; ++sp) {
@@ -213,14 +289,20 @@ int launch_gemm_tn8(const bf16* A, int lda, const bf16* B, int ldb, int M, int N
     if (cost < best_cost * 0.98) { best_cost = cost; best = sp; }
   }
   p.slots_per_split = (p.slots_total + best - 1) / best;
-  if (p.slots_per_split < TN8_NSLOT) p.slots_per_split = TN8_NSLOT;
+  if (p.slots_per_split < nslot) p.slots_per_split = nslot;
   int splits = (p.slots_total + p.slots_per_split - 1) / p.slots_per_split;
   // a trailing split shorter than the ring would under-fill the prologue: merge it into its neighbour
-  if (splits > 1 && p.slots_total - (splits - 1) * p.slots_per_split < TN8_NSLOT) {
+  if (splits > 1 && p.slots_total - (splits - 1) * p.slots_per_split < nslot) {
     p.slots_per_split = (p.slots_total + splits - 2) / (splits - 1);
     splits = (p.slots_total + p.slots_per_split - 1) / p.slots_per_split;
   }
-  if (p.swap) hipLaunchKernelGGL(gemm_tn8_kernel<true>, dim3(tiles * splits), dim3(512), 0, stream, p);
-  else hipLaunchKernelGGL(gemm_tn8_kernel<false>, dim3(tiles * splits), dim3(512), 0, stream, p);
+  const dim3 grid(tiles * splits), block(512);
+  if (yf == 6) {
+    if (p.swap) hipLaunchKernelGGL((gemm_tn8_kernel<true, 6>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_tn8_kernel<false, 6>), grid, block, 0, stream, p);
+  } else {
+    if (p.swap) hipLaunchKernelGGL((gemm_tn8_kernel<true, 4>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((gemm_tn8_kernel<false, 4>), grid, block, 0, stream, p);
+  }
   return mdt_check_launch("gemm_tn8");
 }

@@ -210,92 +210,6 @@ __global__ __launch_bounds__(256) void ln_modulate_bwd_kernel(const bf16* __rest
 }
 
 // ------------------------------------------------------------------------------------------
-// Fused form, round 2: same arithmetic as ln_modulate_bwd_kernel<true>, but the four per-column running sums (d shift,
-// d scale, d gate, d bias of the gated branch) live in LDS and are updated with ds_add_f32 instead of sitting in 80
-// VGPRs per lane: 214 -> ~100 registers, i.e. 4 waves per SIMD instead of 2 (the register-resident version was SLOWER
-// than the two separate kernels: 215 vs 157 us at micro-batch 256).  One pass moves 18 B/element (dxn 2, x 4, dx in +
-// out 8, y 2, dys 2) instead of 14 + 8 for mdt_ln_modulate_bwd followed by mdt_gate_bwd.
-__global__ __launch_bounds__(256, 4) void ln_modulate_bwd_gate_lds_kernel(
-    const bf16* __restrict__ dxn, const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ scale,
-    int mod_ld, int rows_per_sample, int chunk, float* __restrict__ dx, int accumulate, float* __restrict__ dshift,
-    float* __restrict__ dscale, int dmod_ld, int D, const bf16* __restrict__ gy, const float* __restrict__ ggate, int ggate_ld,
-    bf16* __restrict__ gdys, float* __restrict__ gdgate, int gdgate_ld, float* __restrict__ gdbias) {
-  __shared__ float red[4][MAXV * 256];  // [d shift | d scale | d gate | d bias][column]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.x;
-  const int r_begin = blockIdx.y * chunk, r_end = min(r_begin + chunk, rows_per_sample);
-  const int nv = D >> 2;
-  for (int c = threadIdx.x; c < 4 * MAXV * 256; c += 256) (&red[0][0])[c] = 0.f;
-  __syncthreads();
-  const float* sc = scale + (long)b * mod_ld;
-  const float* gg_ = ggate + (long)b * ggate_ld;
-  const float invD = 1.f / (float)D;
-  for (int r = r_begin + wave; r < r_end; r += 4) {
-    const long row = (long)b * rows_per_sample + r;
-    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
-    const float* xr = x + row * D;
-    const bf16* gr = dxn + row * D;
-    f32x4 xh[MAXV], gm[MAXV];
-    float c1 = 0.f, c2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int c = lane + 64 * i;
-      if (c < nv) {
-        const f32x4 xv = *(const f32x4*)(xr + 4 * c);
-        const bf16x4 gv = *(const bf16x4*)(gr + 4 * c);
-        const f32x4 sv = *(const f32x4*)(sc + 4 * c);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float g = bf2f(gv[e]);
-          const float h = (xv[e] - mean) * rstd;
-          __hip_atomic_fetch_add(&red[0][4 * c + e], g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_fetch_add(&red[1][4 * c + e], g * h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          const float gmod = g * (1.f + sv[e]);
-          xh[i][e] = h;
-          gm[i][e] = gmod;
-          c1 += gmod;
-          c2 += gmod * h;
-        }
-      }
-    }
-    c1 = wave_sum(c1) * invD;
-    c2 = wave_sum(c2) * invD;
-    float* dr = dx + row * D;
-#pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
-      const int c = lane + 64 * i;
-      if (c < nv) {
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rstd * (gm[i][e] - c1 - xh[i][e] * c2);
-        if (accumulate) {
-          const f32x4 pv = *(const f32x4*)(dr + 4 * c);
-          o[0] += pv[0]; o[1] += pv[1]; o[2] += pv[2]; o[3] += pv[3];
-        }
-        *(f32x4*)(dr + 4 * c) = o;
-        const bf16x4 yv = *(const bf16x4*)(gy + row * D + 4 * c);
-        const f32x4 gt = *(const f32x4*)(gg_ + 4 * c);
-        bf16x4 dy;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          dy[e] = f2bf(o[e] * gt[e]);
-          __hip_atomic_fetch_add(&red[2][4 * c + e], o[e] * bf2f(yv[e]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_fetch_add(&red[3][4 * c + e], bf2f(dy[e]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        *(bf16x4*)(gdys + row * D + 4 * c) = dy;
-      }
-    }
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < D; c += 256) {
-    atomic_add_f32(dshift + (long)b * dmod_ld + c, red[0][c]);
-    atomic_add_f32(dscale + (long)b * dmod_ld + c, red[1][c]);
-    atomic_add_f32(gdgate + (long)b * gdgate_ld + c, red[2][c]);
-    if (gdbias) atomic_add_f32(gdbias + c, red[3][c]);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // One workgroup per (sample b, 128-column strip): 256 threads = 32 column quads x 8 row lanes; a
 // thread streams rows rl, rl+8, ... (4-way unrolled so several 16-byte loads are in flight),
 // keeps its dgate / dbias partial sums in registers, and the 8 row lanes are combined through
@@ -439,14 +353,9 @@ extern "C" int mdt_ln_modulate_bwd_gate(const mdt_bf16* dxn, const float* x, con
   int B = M / rows_per_sample;
   int chunk = pick_chunk(B, rows_per_sample);
   dim3 grid(B, cdiv(rows_per_sample, chunk));
-  if (mdt_get_tuning_int(MDT_TUNE_LN_GATE_REGS))  // A/B knob "ln_gate_regs": the register-accumulator build of round 1
-    hipLaunchKernelGGL(ln_modulate_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dxn, x, stats,
-                       scale, mod_ld, rows_per_sample, chunk, dx, accumulate, dshift, dscale, dmod_ld, D, (const bf16*)y,
-                       gate, gate_ld, (bf16*)dys, dgate, dgate_ld, dbias);
-  else
-    hipLaunchKernelGGL(ln_modulate_bwd_gate_lds_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dxn, x, stats,
-                       scale, mod_ld, rows_per_sample, chunk, dx, accumulate, dshift, dscale, dmod_ld, D, (const bf16*)y,
-                       gate, gate_ld, (bf16*)dys, dgate, dgate_ld, dbias);
+  hipLaunchKernelGGL(ln_modulate_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dxn, x, stats,
+                     scale, mod_ld, rows_per_sample, chunk, dx, accumulate, dshift, dscale, dmod_ld, D, (const bf16*)y,
+                     gate, gate_ld, (bf16*)dys, dgate, dgate_ld, dbias);
   return mdt_check_launch("ln_modulate_bwd_gate");
 }
 

@@ -43,10 +43,13 @@ MODEL_CONFIGS = {  # models/maskdit.py:649-715  name -> (depth, hidden, patch, h
 }
 YPAD = 1024  # label one-hot width padded to a multiple of 128 for the GEMMs
 LIVE_ENGINES: 'weakref.WeakSet' = weakref.WeakSet()  # lets the optimizer map a parameter view back to its arena
-# mdt_ln_modulate_bwd_gate (LayerNorm backward + the following residual-gate backward in one pass) saves 4 of
-# 22 B/element but needs 214 VGPRs (2 waves/SIMD): measured 215 us vs 111 + 46 us for the two separate
-# kernels on XL/2, so the plans use the separate kernels.  Flip to re-measure after a register diet.
-FUSE_LN_GATE = os.environ.get('MDT_FUSE_LN_GATE', '0') == '1'  # A/B switch; round 2 rebuilt the kernel on LDS accumulators
+# mdt_ln_modulate_bwd_gate (LayerNorm backward + the following residual-gate backward in one pass) moves 18 instead of
+# 22 B/element but needs 214 VGPRs for its four per-column running sums (2 waves/SIMD): 705 us vs 668 us for the two
+# separate kernels at micro-batch 1024 (XL/2 encoder rows), so the plans use the separate kernels.  Moving the sums
+# into LDS (ds_add_f32, 122 VGPRs, 4 waves/SIMD) was measured at 3017 us -- LDS float atomics are far too slow for
+# 80 updates per lane per row -- and was dropped (round 2, tools/ln_gate_bench.py).  MDT_FUSE_LN_GATE=1 re-enables
+# the fused launch for A/B runs.
+FUSE_LN_GATE = os.environ.get('MDT_FUSE_LN_GATE', '0') == '1'
 ADA_GROUP = 7  # encoder blocks per adaLN weight-gradient group (XL/2: 4 groups of 7 + the decoder-side group)
 FUSE_COLSUM = os.environ.get('MDT_FUSE_COLSUM', '1') != '0'  # fc1 bias gradient out of the DGELU epilogue (A/B switch)
 

@@ -143,24 +143,29 @@ def test_gemm_tn(M, N1, N2, splits):
     close(Cc, ref, 1e-5, f'gemm_tn {M}x{N1}x{N2}')
 
 
-@pytest.mark.parametrize('M,N1,N2', [(8192, 1152, 384), (8192, 384, 1152), (8320, 640, 512), (16384, 512, 2048)])
+@pytest.mark.parametrize('M,N1,N2', [(8192, 1152, 384), (8192, 384, 1152), (8320, 640, 512), (16384, 512, 2048),
+                                     (8192, 1152, 4608), (8384, 3456, 1152), (8192, 1536, 512), (12352, 1152, 1152)])
 def test_gemm_tn8_pipelined(M, N1, N2):
-    """Large weight-gradient shapes take the 256x128 ring-pipelined kernel (gemm_tn8.hip): ragged
-    256-wide tiles (1152 = 4.5 x 256), the operand-swapped store path (N2 takes the 256 role) and a
-    slot count that is not a multiple of the ring length; cross-checked against the 128x128 kernel."""
+    """Large weight-gradient shapes take the ring-pipelined kernel (gemm_tn8.hip) in its 256x192 shape when a width
+    divides by 192 (every XL/2 encoder weight gradient) and in the 256x128 shape otherwise: ragged 256-wide tiles
+    (1152 = 4.5 x 256, 3456 = 13.5 x 256), the operand-swapped store path and slot counts that are not a multiple of
+    the ring length; cross-checked against the 128x128 kernel and, shape against shape, through the `tn8_wide` knob."""
     torch.manual_seed(21)
     A = bf(torch.randn(M, N1, device=DEV))
     Bm = bf(torch.randn(M, N2, device=DEV))
     ref = A.float().t() @ Bm.float() + 1.0
     got = {}
-    for v in (1, 0):
+    for v, wide in ((1, 0), (0, 1), (0, 0)):
         _lib.lib().mdt_set_tuning(b'gemm_tn_variant', v)
+        _lib.lib().mdt_set_tuning(b'tn8_wide', wide)
         Cc = torch.ones(N1, N2, device=DEV)
         ops.gemm_tn(A, Bm, Cc)
-        got[v] = Cc
+        got[v, wide] = Cc
     _lib.lib().mdt_set_tuning(b'gemm_tn_variant', 0)
-    close(got[0], ref, 1e-5, f'gemm_tn8 {M}x{N1}x{N2}')
-    close(got[0], got[1], 1e-5, 'gemm_tn8 vs 128x128 kernel')
+    _lib.lib().mdt_set_tuning(b'tn8_wide', 0)
+    close(got[0, 0], ref, 1e-5, f'gemm_tn8 {M}x{N1}x{N2}')
+    close(got[0, 1], ref, 1e-5, f'gemm_tn8 256x128 only {M}x{N1}x{N2}')
+    close(got[0, 0], got[1, 0], 1e-5, 'gemm_tn8 vs 128x128 kernel')
     # asymmetric operand: A^T picks rows of B (detects transposed / permuted stores)
     A2 = torch.zeros(M, N1, device=DEV)
     A2[torch.arange(N1), torch.arange(N1)] = 1.0

@@ -1,5 +1,4 @@
-"""LayerNorm-modulate backward + residual-gate backward: two kernels vs the fused kernel (LDS accumulators, and the
-round-1 register-accumulator build behind the `ln_gate_regs` knob).  Run on the GPU box:
+"""LayerNorm-modulate backward + residual-gate backward: two kernels vs the fused kernel.  Run on the GPU box:
     python tools/ln_gate_bench.py [micro_batch]"""
 import os
 import sys
@@ -8,7 +7,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from maskdit_amd import ops  # noqa: E402
-from maskdit_amd._lib import call, lib  # noqa: E402
+from maskdit_amd._lib import call  # noqa: E402
 
 DEV = 'cuda'
 
@@ -60,11 +59,7 @@ def main():
     t = timeit(separate)
     print(f'separate (22 B/el)      {t:8.1f} us  {22 * el / t / 1e6:6.2f} TB/s')
     t = timeit(fused)
-    print(f'fused, LDS sums (18 B)  {t:8.1f} us  {18 * el / t / 1e6:6.2f} TB/s')
-    lib().mdt_set_tuning(b'ln_gate_regs', 1)
-    t = timeit(fused)
-    print(f'fused, reg sums (18 B)  {t:8.1f} us  {18 * el / t / 1e6:6.2f} TB/s')
-    lib().mdt_set_tuning(b'ln_gate_regs', 0)
+    print(f'fused (18 B/el)         {t:8.1f} us  {18 * el / t / 1e6:6.2f} TB/s')
 
 
 if __name__ == '__main__':
