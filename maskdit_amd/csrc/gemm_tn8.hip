@@ -47,6 +47,7 @@ struct TN8Params {
   int slots_total;     // contraction rows / 32
   int slots_per_split;
   int tiles_x, tiles_y;
+  int dbg;             // timing experiments only (knob tn8_dbg): 1 = no slot refills, 2 = no fragment reads, 4 = refills re-read the first slots
 };
 
 // ds_read_b64_tr_b16 through inline asm: with the builtin, hipcc's waitcnt pass assumes the read may
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TN8Params p) {
   char* const lds_w = smem + wave * 1024;
 
   auto issue = [&](int slot, int s) {  // fill ring slot `slot` with contraction rows of phase s
+    if (p.dbg & 4) s &= 7;  // timing experiment: re-read the first 8 slots (cache-resident source)
     char* base = lds_w + slot * SLOT_BYTES;
     glds16(xu + s * x_step + opaque(x_lo0), base);
     glds16(xu + s * x_step + opaque(x_lo1), base + 8192);
@@ -129,6 +131,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TN8Params p) {
   // extra barrier before the loop, waves 0-3 one after it.  Consequence for the ring protocol: a slot read by waves
   // 0-3 in their half A of phase ph+1 needs waves 4-7's portion published one half earlier, so the late group waits
   // for one slot more (NSLOT-3 outstanding instead of NSLOT-2).
+  // Measured alternatives at 131072 x 1152 x 4608 (tools/tn8_bench.py; this form 1165 us): lock-step waves 1233 us;
+  // no stagger but one memory instruction pinned after each MFMA 1280 us; an L2 prefetch stream (one divergent dword
+  // load per wave and phase touching the lines of the slot NSLOT phases ahead) 1719 us -- the extra vector-memory
+  // instruction delays the DMAs queued behind it far more than the earlier L2 fill saves.  Where the time goes (knob
+  // tn8_dbg): MFMAs + barriers alone 828 us, + transpose reads 871, + refills from cache-resident rows 1020, + refills
+  // of the real stream (HBM latency) 1165.
   const bool late = wave >= 4;
 #define TN8_WAIT_PHASE()                                          \
   {                                                               \
@@ -185,6 +193,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TN8Params p) {
     _Pragma("unroll") for (int j = 4; j < YF; ++j)                                                      \
       Yr[set][j] = cat4(tn8_tr_read<so>(ya[(slot) / 3][j]), tn8_tr_read<so + 512>(ya[(slot) / 3][j])); \
   }
+#define TN8_MFMA(set, i, j)                                                                             \
+  acc[i][j] = SWAP ? mfma16(Yr[set][j], Xr[set][i], acc[i][j]) : mfma16(Xr[set][i], Yr[set][j], acc[i][j]);
 
   // ---- prologue: fill the ring in steady-state order, wait for slots 0..2, load the fragments of slot 0
 #pragma unroll
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TN8Params p) {
   TN8_WAIT_SLOTS(NSLOT - 3)
   TN8_BARRIER()
   TN8_LOAD(0, 0)
-  tn8_wait<63>();  // lgkmcnt(0): every wave's reads of slot 0 retired before the early group refills it
+  tn8_wait<63>();  // lgkmcnt(0): every wave's reads of slot 0 retired before it is refilled
   TN8_BARRIER()
   if (late) TN8_BARRIER()
 
@@ -201,23 +211,24 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TN8Params p) {
   if constexpr ((K) < Cfg::UNROLL) {                                                                    \
     const int ph = g0 + (K);                                                                            \
     if (ph < S) {                                                                                       \
-      /* half A (1) fragments of the next phase */                                                      \
-      if (ph + 1 < S) TN8_LOAD(((K) + 1) & 1, ((K) + 1) % NSLOT)                                        \
-      /* (2) slot K was read during the previous phase: refill it with the rows of phase ph+NSLOT */    \
-      if (ph + NSLOT < S) issue((K) % NSLOT, ph + NSLOT);                                               \
-      tn8_wait<63>(); /* lgkmcnt(0): the other group refills the slot just read in ITS next half A */   \
-      TN8_BARRIER()                                                                                     \
-      /* half B (3) this phase's MFMAs */                                                               \
-      __builtin_amdgcn_s_setprio(1);                                                                    \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
-      _Pragma("unroll") for (int j = 0; j < YF; ++j)                                                    \
-        acc[i][j] = SWAP ? mfma16(Yr[(K) & 1][j], Xr[(K) & 1][i], acc[i][j])                            \
-                         : mfma16(Xr[(K) & 1][i], Yr[(K) & 1][j], acc[i][j]);                           \
-      __builtin_amdgcn_s_setprio(0);                                                                    \
-      /* (4) publish this wave's share of the slot read two (early group) / three (late group) halves on */ \
-      if (ph + NSLOT + 1 <= S) TN8_WAIT_PHASE()                                                         \
-      else tn8_wait<0>();                                                                               \
-      TN8_BARRIER()                                                                                     \
+      const bool do_reads = ph + 1 < S && !(p.dbg & 2), do_dma = ph + NSLOT < S && !(p.dbg & 1);                                      \
+      {                                                                                                 \
+        /* half A (1) fragments of the next phase */                                                    \
+        if (do_reads) TN8_LOAD(((K) + 1) & 1, ((K) + 1) % NSLOT)                                        \
+        /* (2) slot K was read during the previous phase: refill it with the rows of phase ph+NSLOT */  \
+        if (do_dma) issue((K) % NSLOT, ph + NSLOT);                                                     \
+        tn8_wait<63>(); /* lgkmcnt(0): the other group refills the slot just read in ITS next half A */ \
+        TN8_BARRIER()                                                                                   \
+        /* half B (3) this phase's MFMAs */                                                             \
+        __builtin_amdgcn_s_setprio(1);                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
+        _Pragma("unroll") for (int j = 0; j < YF; ++j) TN8_MFMA((K) & 1, i, j)                          \
+        __builtin_amdgcn_s_setprio(0);                                                                  \
+        /* (4) publish this wave's share of the slot read two (early group) / three (late group) halves on */ \
+        if (ph + NSLOT + 1 <= S) TN8_WAIT_PHASE()                                                       \
+        else tn8_wait<0>();                                                                             \
+        TN8_BARRIER()                                                                                   \
+      }                                                                                                 \
     }                                                                                                   \
   }
   for (int g0 = 0; g0 < S; g0 += Cfg::UNROLL) {
@@ -227,6 +238,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TN8Params p) {
   if (!late) TN8_BARRIER()
 #undef TN8_PHASE
 #undef TN8_LOAD
+#undef TN8_MFMA
 #undef TN8_WAIT_SLOTS
 #undef TN8_WAIT_PHASE
 #undef TN8_BARRIER
@@ -273,6 +285,7 @@ int launch_gemm_tn8(const bf16* A, int lda, const bf16* B, int ldb, int M, int N
   if (a_is_x) { p.X = A; p.ldx = lda; p.NX = N1; p.Y = B; p.ldy = ldb; p.NY = N2; p.swap = 0; }
   else { p.X = B; p.ldx = ldb; p.NX = N2; p.Y = A; p.ldy = lda; p.NY = N1; p.swap = 1; }
   p.C = C; p.ldc = ldc;
+  p.dbg = mdt_get_tuning_int(MDT_TUNE_TN8_DBG);
   const int nslot = yf == 6 ? TN8Cfg<6>::NSLOT : TN8Cfg<4>::NSLOT;
   p.tiles_x = (p.NX + 255) / 256;
   p.tiles_y = p.NY / (32 * yf);
@@ -297,12 +310,9 @@ int launch_gemm_tn8(const bf16* A, int lda, const bf16* B, int ldb, int M, int N
     splits = (p.slots_total + p.slots_per_split - 1) / p.slots_per_split;
   }
   const dim3 grid(tiles * splits), block(512);
-  if (yf == 6) {
-    if (p.swap) hipLaunchKernelGGL((gemm_tn8_kernel<true, 6>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_tn8_kernel<false, 6>), grid, block, 0, stream, p);
-  } else {
-    if (p.swap) hipLaunchKernelGGL((gemm_tn8_kernel<true, 4>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((gemm_tn8_kernel<false, 4>), grid, block, 0, stream, p);
-  }
+#define TN8_LAUNCH(SW, YFV) hipLaunchKernelGGL((gemm_tn8_kernel<SW, YFV>), grid, block, 0, stream, p)
+  if (yf == 6) { if (p.swap) TN8_LAUNCH(true, 6); else TN8_LAUNCH(false, 6); }
+  else { if (p.swap) TN8_LAUNCH(true, 4); else TN8_LAUNCH(false, 4); }
+#undef TN8_LAUNCH
   return mdt_check_launch("gemm_tn8");
 }
