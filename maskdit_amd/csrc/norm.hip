@@ -210,6 +210,137 @@ __global__ __launch_bounds__(256) void ln_modulate_bwd_kernel(const bf16* __rest
 }
 
 // ------------------------------------------------------------------------------------------
+// Column-split form of the fused LayerNorm-modulate + residual-gate backward (round 2).  The row-per-wave kernel above
+// needs 4 x 20 per-column running sums per lane (214 VGPRs, 2 waves/SIMD) and loses to the two separate kernels.  Here
+// a PAIR of waves shares a row, each wave one half of the columns: 4 x 12 running sums per lane, the two row
+// statistics (sum g', sum g' xhat) are exchanged through LDS with one workgroup barrier per row.  Workgroup = 2 pairs;
+// pair p takes rows r_begin + p, + 2, ...  18 B/element in one pass instead of 14 + 8 in two.
+#define HV 3  // float4 per lane and half row => D <= 1536
+__global__ __launch_bounds__(256, 3) void ln_bwd_gate_split_kernel(
+    const bf16* __restrict__ dxn, const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ scale,
+    int mod_ld, int rows_per_sample, int chunk, float* __restrict__ dx, int accumulate, float* __restrict__ dshift,
+    float* __restrict__ dscale, int dmod_ld, int D, const bf16* __restrict__ gy, const float* __restrict__ ggate, int ggate_ld,
+    bf16* __restrict__ gdys, float* __restrict__ gdgate, int gdgate_ld, float* __restrict__ gdbias) {
+  __shared__ float part[2][2][2][2];        // [iteration parity][pair][half][sum g', sum g' xhat]
+  __shared__ float red[2][2][MAXV * 256];   // [sum kind][pair][column]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int pair = wave >> 1, hw = wave & 1;
+  const int b = blockIdx.x;
+  const int r_begin = blockIdx.y * chunk, r_end = min(r_begin + chunk, rows_per_sample);
+  const int nvh = D >> 3;        // float4 per half row
+  const int q0 = hw * nvh;       // first float4 of this wave's half
+  const float* sc = scale + (long)b * mod_ld;
+  const float* gg_ = ggate + (long)b * ggate_ld;
+  f32x4 a_sh[HV], a_sc[HV], a_g[HV], a_b[HV];
+#pragma unroll
+  for (int i = 0; i < HV; ++i) {
+    a_sh[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    a_sc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    a_g[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    a_b[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const float invD = 1.f / (float)D;
+  const int iters = (r_end - r_begin + 1) >> 1;
+  for (int it = 0; it < iters; ++it) {
+    const int r = r_begin + 2 * it + pair;
+    const bool valid = r < r_end;  // wave-uniform; only the last iteration of an odd chunk has an idle pair
+    const long row = (long)b * rows_per_sample + (valid ? r : r_begin);
+    float mean = 0.f, rstd = 0.f;
+    f32x4 xh[HV], gm[HV], pv[HV];
+    bf16x4 yv[HV];
+    float c1 = 0.f, c2 = 0.f;
+    if (valid) {
+      mean = stats[2 * row];
+      rstd = stats[2 * row + 1];
+      const float* xr = x + row * D;
+      const bf16* gr = dxn + row * D;
+#pragma unroll
+      for (int i = 0; i < HV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nvh) {
+          const f32x4 xv = *(const f32x4*)(xr + 4 * (q0 + c));
+          const bf16x4 gv = *(const bf16x4*)(gr + 4 * (q0 + c));
+          const f32x4 sv = *(const f32x4*)(sc + 4 * (q0 + c));  // per-sample vector: L1 / L2 resident
+          // the second half's operands do not depend on the row statistics: issue their loads now
+          pv[i] = accumulate ? *(const f32x4*)(dx + row * D + 4 * (q0 + c)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+          yv[i] = *(const bf16x4*)(gy + row * D + 4 * (q0 + c));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float g = bf2f(gv[e]);
+            const float h = (xv[e] - mean) * rstd;
+            a_sh[i][e] += g;
+            a_sc[i][e] += g * h;
+            const float gmod = g * (1.f + sv[e]);
+            xh[i][e] = h;
+            gm[i][e] = gmod;
+            c1 += gmod;
+            c2 += gmod * h;
+          }
+        }
+      }
+    }
+    c1 = wave_sum(c1);
+    c2 = wave_sum(c2);
+    if (lane == 0) {
+      part[it & 1][pair][hw][0] = c1;
+      part[it & 1][pair][hw][1] = c2;
+    }
+    __syncthreads();
+    c1 = (part[it & 1][pair][0][0] + part[it & 1][pair][1][0]) * invD;
+    c2 = (part[it & 1][pair][0][1] + part[it & 1][pair][1][1]) * invD;
+    if (valid) {
+      float* dr = dx + row * D;
+#pragma unroll
+      for (int i = 0; i < HV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nvh) {
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = pv[i][e] + rstd * (gm[i][e] - c1 - xh[i][e] * c2);
+          *(f32x4*)(dr + 4 * (q0 + c)) = o;
+          const f32x4 gt = *(const f32x4*)(gg_ + 4 * (q0 + c));
+          bf16x4 dy;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            a_g[i][e] += o[e] * bf2f(yv[i][e]);
+            dy[e] = f2bf(o[e] * gt[e]);
+            a_b[i][e] += bf2f(dy[e]);
+          }
+          *(bf16x4*)(gdys + row * D + 4 * (q0 + c)) = dy;
+        }
+      }
+    }
+  }
+  // combine the two pairs' per-column partials, one atomic per column per workgroup (two sum kinds at a time)
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    if (k) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < HV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nvh) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          red[0][pair][4 * (q0 + c) + e] = k ? a_g[i][e] : a_sh[i][e];
+          red[1][pair][4 * (q0 + c) + e] = k ? a_b[i][e] : a_sc[i][e];
+        }
+      }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+      const float s0 = red[0][0][c] + red[0][1][c], s1 = red[1][0][c] + red[1][1][c];
+      if (!k) {
+        atomic_add_f32(dshift + (long)b * dmod_ld + c, s0);
+        atomic_add_f32(dscale + (long)b * dmod_ld + c, s1);
+      } else {
+        atomic_add_f32(gdgate + (long)b * gdgate_ld + c, s0);
+        if (gdbias) atomic_add_f32(gdbias + c, s1);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // One workgroup per (sample b, 128-column strip): 256 threads = 32 column quads x 8 row lanes; a
 // thread streams rows rl, rl+8, ... (4-way unrolled so several 16-byte loads are in flight),
 // keeps its dgate / dbias partial sums in registers, and the 8 row lanes are combined through
@@ -353,9 +484,14 @@ extern "C" int mdt_ln_modulate_bwd_gate(const mdt_bf16* dxn, const float* x, con
   int B = M / rows_per_sample;
   int chunk = pick_chunk(B, rows_per_sample);
   dim3 grid(B, cdiv(rows_per_sample, chunk));
-  hipLaunchKernelGGL(ln_modulate_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dxn, x, stats,
-                     scale, mod_ld, rows_per_sample, chunk, dx, accumulate, dshift, dscale, dmod_ld, D, (const bf16*)y,
-                     gate, gate_ld, (bf16*)dys, dgate, dgate_ld, dbias);
+  if (D % 8 == 0 && !mdt_get_tuning_int(MDT_TUNE_LN_GATE_ROWWISE))  // knob "ln_gate_rowwise": the row-per-wave build (A/B)
+    hipLaunchKernelGGL(ln_bwd_gate_split_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dxn, x, stats,
+                       scale, mod_ld, rows_per_sample, chunk, dx, accumulate, dshift, dscale, dmod_ld, D, (const bf16*)y,
+                       gate, gate_ld, (bf16*)dys, dgate, dgate_ld, dbias);
+  else
+    hipLaunchKernelGGL(ln_modulate_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dxn, x, stats,
+                       scale, mod_ld, rows_per_sample, chunk, dx, accumulate, dshift, dscale, dmod_ld, D, (const bf16*)y,
+                       gate, gate_ld, (bf16*)dys, dgate, dgate_ld, dbias);
   return mdt_check_launch("ln_modulate_bwd_gate");
 }
 

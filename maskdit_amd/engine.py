@@ -43,13 +43,13 @@ MODEL_CONFIGS = {  # models/maskdit.py:649-715  name -> (depth, hidden, patch, h
 }
 YPAD = 1024  # label one-hot width padded to a multiple of 128 for the GEMMs
 LIVE_ENGINES: 'weakref.WeakSet' = weakref.WeakSet()  # lets the optimizer map a parameter view back to its arena
-# mdt_ln_modulate_bwd_gate (LayerNorm backward + the following residual-gate backward in one pass) moves 18 instead of
-# 22 B/element but needs 214 VGPRs for its four per-column running sums (2 waves/SIMD): 705 us vs 668 us for the two
-# separate kernels at micro-batch 1024 (XL/2 encoder rows), so the plans use the separate kernels.  Moving the sums
-# into LDS (ds_add_f32, 122 VGPRs, 4 waves/SIMD) was measured at 3017 us -- LDS float atomics are far too slow for
-# 80 updates per lane per row -- and was dropped (round 2, tools/ln_gate_bench.py).  MDT_FUSE_LN_GATE=1 re-enables
-# the fused launch for A/B runs.
-FUSE_LN_GATE = os.environ.get('MDT_FUSE_LN_GATE', '0') == '1'
+# mdt_ln_modulate_bwd_gate: LayerNorm backward + the following residual-gate backward in one pass, 18 instead of
+# 14 + 8 B/element.  Round 2's column-split kernel (a pair of waves per row, 4 x 12 instead of 4 x 20 running sums per
+# lane, second-half loads issued before the row reduction): 631 vs 726 us for the pair on the XL/2 encoder rows at
+# micro-batch 1024, 538 vs 606 us on the decoder rows (tools/ln_gate_bench.py); whole step 520.0 -> 518.5 ms on the
+# same box.  History: the row-per-wave build (214 VGPRs) lost to the separate kernels (705-762 us), an LDS-atomics
+# build was 4x slower (3017 us).  MDT_FUSE_LN_GATE=0 selects the two separate kernels (A/B runs).
+FUSE_LN_GATE = os.environ.get('MDT_FUSE_LN_GATE', '1') != '0'
 ADA_GROUP = 7  # encoder blocks per adaLN weight-gradient group (XL/2: 4 groups of 7 + the decoder-side group)
 FUSE_COLSUM = os.environ.get('MDT_FUSE_COLSUM', '1') != '0'  # fc1 bias gradient out of the DGELU epilogue (A/B switch)
 

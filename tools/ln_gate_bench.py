@@ -7,7 +7,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from maskdit_amd import ops  # noqa: E402
-from maskdit_amd._lib import call  # noqa: E402
+from maskdit_amd._lib import call, lib  # noqa: E402
 
 DEV = 'cuda'
 
@@ -31,7 +31,7 @@ def timeit(fn, n=20):
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-    L, D = 128, 1152
+    L, D = (128, 1152) if len(sys.argv) < 3 else (256, 512)
     M = B * L
     torch.manual_seed(0)
     x = torch.randn(M, D, device=DEV)
@@ -59,7 +59,11 @@ def main():
     t = timeit(separate)
     print(f'separate (22 B/el)      {t:8.1f} us  {22 * el / t / 1e6:6.2f} TB/s')
     t = timeit(fused)
-    print(f'fused (18 B/el)         {t:8.1f} us  {18 * el / t / 1e6:6.2f} TB/s')
+    print(f'fused, column-split     {t:8.1f} us  {18 * el / t / 1e6:6.2f} TB/s  (18 B/el)')
+    lib().mdt_set_tuning(b'ln_gate_rowwise', 1)
+    t = timeit(fused)
+    print(f'fused, row per wave     {t:8.1f} us  {18 * el / t / 1e6:6.2f} TB/s  (18 B/el)')
+    lib().mdt_set_tuning(b'ln_gate_rowwise', 0)
 
 
 if __name__ == '__main__':
