@@ -532,6 +532,19 @@ __device__ __forceinline__ void sp_load(SpRegs<HD, ROWS>& t, const bf16* g, long
     }
   }
 }
+// the same without a lane-dependent branch: out-of-range lanes re-read the tile's last chunk (never stored to LDS).
+// A load inside a divergent block makes hipcc's waitcnt pass fall back to vmcnt(0) at the consumer, which also waits
+// for every store issued in between (attn_bwd_sp_kernel keeps its dQ / dK / dV stores in flight across items).
+template <int HD, int ROWS>
+__device__ __forceinline__ void sp_load_nb(SpRegs<HD, ROWS>& t, const bf16* g, long ld, int tid) {
+  constexpr int CH = SpCfg<HD>::CH;
+#pragma unroll
+  for (int i = 0; i < SpRegs<HD, ROWS>::N; ++i) {
+    const int idx = min(tid + 512 * i, ROWS * CH - 1);
+    const int r = idx / CH, c = idx - r * CH;
+    t.v[i] = *(const bf16x8*)(g + (long)r * ld + c * 8);
+  }
+}
 template <int HD, int ROWS>
 __device__ __forceinline__ void sp_store(const SpRegs<HD, ROWS>& t, char* lds, int tid) {
   constexpr int CH = SpCfg<HD>::CH;
@@ -658,7 +671,7 @@ template <int HD, int KF, int OCC>
 __global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                               const bf16* __restrict__ dout, const float* __restrict__ lse,
                                                               float* __restrict__ delta, bf16* __restrict__ dqkv, int H,
-                                                              float scale, float scale_log2e, int Lv, int B) {
+                                                              float scale, float scale_log2e, int Lv, int B, int dbg) {
   using C = SpCfg<HD>;
   constexpr int L = 128 * KF;
   constexpr int TILE = L * C::PITCH;
@@ -685,26 +698,29 @@ __global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __res
     const bf16* base = qkv + (long)b * L * ld + h * HD;
     const bf16* dobase = dout + (long)b * L * D + h * HD;
     const bf16* obase = out + (long)b * L * D + h * HD;
-    sp_load<HD, L>(r0, base, ld, tid);
-    sp_load<HD, L>(r1, base + D, ld, tid);
-    sp_load<HD, L>(r2, base + 2 * D, ld, tid);
-    sp_load<HD, L>(r3, dobase, D, tid);
-    if (tid < L) lse_r = lse[((long)b * H + h) * L + tid];
+    // every load unconditional (clamped addresses): see sp_load_nb
+    sp_load_nb<HD, L>(r0, base, ld, tid);
+    sp_load_nb<HD, L>(r1, base + D, ld, tid);
+    sp_load_nb<HD, L>(r2, base + 2 * D, ld, tid);
+    sp_load_nb<HD, L>(r3, dobase, D, tid);
+    lse_r = lse[((long)b * H + h) * L + (tid & (L - 1))];
 #pragma unroll
     for (int qi = 0; qi < KF; ++qi) {
       const int q = wave * 16 * KF + 16 * qi + i16;
-      load_frag_global<HD>(of[qi], obase + (long)q * D, g);
-      load_frag_global<HD>(dof[qi], dobase + (long)q * D, g);
+#pragma unroll
+      for (int s = 0; s < C::KSTEPS; ++s) {
+        const int d = min(32 * s + 8 * g, HD - 8);  // tail lanes re-read the last chunk; masked where delta is formed
+        of[qi][s] = *(const bf16x8*)(obase + (long)q * D + d);
+        dof[qi][s] = *(const bf16x8*)(dobase + (long)q * D + d);
+      }
     }
   };
 
-  int item = blockIdx.x;
-  if (item < nitems) fetch(item);
-  for (; item < nitems; item += gridDim.x) {
+  // ---- registers -> LDS (+ delta = rowsum(dO * O) of this wave's queries)
+  auto stage = [&](int it) {
     int b, h;
-    sp_item_coords(item, B, H, b, h);
+    sp_item_coords(it, B, H, b, h);
     const long bh = (long)b * H + h;
-    // ---- registers -> LDS (+ delta = rowsum(dO * O) of this wave's queries)
     sp_store<HD, L>(r0, Qs, tid);
     sp_store<HD, L>(r1, Ks, tid);
     sp_store<HD, L>(r2, Vs, tid);
@@ -715,22 +731,40 @@ __global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __res
       const int q = wave * 16 * KF + 16 * qi + i16;
       float dl = 0.f;
 #pragma unroll
-      for (int s = 0; s < C::KSTEPS; ++s)
+      for (int s = 0; s < C::KSTEPS; ++s) {
+        float part = 0.f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dl += bf2f(dof[qi][s][e]) * bf2f(of[qi][s][e]);
+        for (int e = 0; e < 8; ++e) part += bf2f(dof[qi][s][e]) * bf2f(of[qi][s][e]);
+        dl += (32 * s + 8 * g < HD) ? part : 0.f;
+      }
       dl = group_sum(dl);
       if (g == 0) {
         del_s[q] = dl;
         delta[bh * L + q] = dl;
       }
     }
+  };
+
+  // The loop is rotated: the first item is fetched and staged up front, every later item is staged at the END of the
+  // previous iteration.  That staging then always follows [19 loads, 15 stores] in issue order, so hipcc's counted
+  // vmcnt leaves the stores in flight; with the staging at the loop top the entry path (loads only) forced vmcnt(0)
+  // on the back edge as well and every item waited for its predecessor's dQ stores.
+  int item = blockIdx.x;
+  if (item >= nitems) return;
+  fetch(item);
+  stage(item);
+  for (;;) {
+    int b, h;
+    sp_item_coords(item, B, H, b, h);
     __syncthreads();
+    const bool has_next = OCC == 2 && item + (int)gridDim.x < nitems;
     // ---- the next item's loads fly under this item's arithmetic (persistent form only)
-    if (OCC == 2 && item + (int)gridDim.x < nitems) fetch(item + gridDim.x);
+    if (has_next && !(dbg & 2)) fetch(item + gridDim.x);
+    __builtin_amdgcn_sched_barrier(0);
 
     // ---- phase A: this wave's keys -> dK, dV (S fragments: rows = queries 16f + 4g + r, col = key i16)
 #pragma unroll 1
-    for (int ki = 0; ki < KF; ++ki) {
+    for (int ki = 0; ki < ((dbg & 4) ? 0 : KF); ++ki) {
       const int k0 = wave * 16 * KF + 16 * ki;
       bf16x8 kf[C::KSTEPS], vf[C::KSTEPS];
 #pragma unroll
@@ -780,7 +814,7 @@ __global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __res
 #pragma unroll
       for (int f = 0; f < C::NFRAG; ++f) {
         const int d = 16 * f + 4 * g;
-        if (d < HD) {
+        if (d < HD && !(dbg & 1)) {
           bf16x4 a, c;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -795,7 +829,7 @@ __global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __res
 
     // ---- phase B: this wave's queries -> dQ (S^T fragments: rows = keys 16f + 4g + r, col = query i16)
 #pragma unroll 1
-    for (int qi = 0; qi < KF; ++qi) {
+    for (int qi = 0; qi < ((dbg & 8) ? 0 : KF); ++qi) {
       const int q = wave * 16 * KF + 16 * qi + i16;
       bf16x8 qf[C::KSTEPS], dqo[C::KSTEPS];
 #pragma unroll
@@ -835,7 +869,7 @@ __global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __res
 #pragma unroll
       for (int f = 0; f < C::NFRAG; ++f) {
         const int d = 16 * f + 4 * g;
-        if (d < HD) {
+        if (d < HD && !(dbg & 1)) {
           bf16x4 v;
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = f2bf(dq[f][r]);
@@ -843,10 +877,284 @@ __global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __res
         }
       }
     }
-    if (OCC != 2) break;  // one item per workgroup
-    __syncthreads();      // every wave is done with the tiles before the next item overwrites them
-    if (OCC == 2 && !(item + (int)gridDim.x < nitems)) break;
+    if (!has_next) break;  // (OCC != 2: one item per workgroup)
+    __syncthreads();       // every wave is done with the tiles before the next item overwrites them
+    item += gridDim.x;
+    stage(item);
   }
+}
+
+// phases A (dK, dV of this wave's 16 keys) and B (dQ of its 16 queries) of one (sample, head) item at L = 128, all
+// operands in LDS (attn_bwd_sp_kernel's arithmetic, KF = 1); `dbase` = dqkv + the item's row / head offset
+template <int HD>
+__device__ __forceinline__ void attn_bwd_item_math(const char* Qs, const char* Ks, const char* Vs, const char* dOs,
+                                                   const float* lse_s, const float* del_s, bf16* dbase, long ld, int D,
+                                                   int wave, int i16, int g, int Lv, float scale, float scale_log2e,
+                                                   bf16x4 (&q_cur)[AttnCfg<HD>::NFRAG], const bf16x4 (&q_prev)[AttnCfg<HD>::NFRAG]) {
+  // Store-data registers.  gfx9 reads a store's data from the VGPRs when the store reaches the memory pipeline, so hipcc
+  // guards every re-use of such a register with a wait for that store -- vmcnt(0) when the store is the youngest
+  // operation, which is exactly the case when the register allocator recycles them a few instructions later.  The
+  // packed dK / dV values therefore stay live (empty asm uses) until the end of phase B, and the dQ values of the
+  // PREVIOUS item (q_prev, owned by the caller) until this item's dK / dV stores are out: by then the stores that read
+  // them are ten or more operations old and the guard is a cheap counted wait.
+  using C = SpCfg<HD>;
+  constexpr int L = 128;
+  bf16x4 kv_keep[2 * C::NFRAG];
+  {
+    const int k0 = wave * 16;
+    bf16x8 kf[C::KSTEPS], vf[C::KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < C::KSTEPS; ++ks) {
+      kf[ks] = sp_frag_rows<HD>(Ks, k0 + i16, ks, g);
+      vf[ks] = sp_frag_rows<HD>(Vs, k0 + i16, ks, g);
+    }
+    f32x4 dk[C::NFRAG], dv[C::NFRAG];
+#pragma unroll
+    for (int f = 0; f < C::NFRAG; ++f) {
+      dk[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dv[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool key_ok = (k0 + i16) < Lv;
+#pragma unroll 1
+    for (int qb = 0; qb < L; qb += 64) {
+      f32x4 pm[4], ds[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < C::KSTEPS; ++ks) {
+          s = mfma16(sp_frag_rows<HD>(Qs, qb + 16 * f + i16, ks, g), kf[ks], s);
+          dp = mfma16(sp_frag_rows<HD>(dOs, qb + 16 * f + i16, ks, g), vf[ks], dp);
+        }
+        const f32x4 ls = *(const f32x4*)(lse_s + qb + 16 * f + 4 * g);
+        const f32x4 dl = *(const f32x4*)(del_s + qb + 16 * f + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = key_ok ? fast_exp2(s[r] * scale_log2e - ls[r]) : 0.f;
+          pm[f][r] = pv;
+          ds[f][r] = pv * (dp[r] - dl[r]) * scale;
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 pf = pack_pair(pm[2 * ks], pm[2 * ks + 1]);
+        const bf16x8 dsf = pack_pair(ds[2 * ks], ds[2 * ks + 1]);
+#pragma unroll
+        for (int f = 0; f < C::NFRAG; ++f) {
+          dv[f] = mfma16(sp_frag_cols<HD>(dOs, qb + 32 * ks, f, i16, g), pf, dv[f]);
+          dk[f] = mfma16(sp_frag_cols<HD>(Qs, qb + 32 * ks, f, i16, g), dsf, dk[f]);
+        }
+      }
+    }
+    bf16* drow = dbase + (long)(k0 + i16) * ld;
+#pragma unroll
+    for (int f = 0; f < C::NFRAG; ++f) {
+      const int d = 16 * f + 4 * g;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        kv_keep[2 * f][r] = f2bf(dk[f][r]);
+        kv_keep[2 * f + 1][r] = f2bf(dv[f][r]);
+      }
+      if (d < HD) {
+        *(bf16x4*)(drow + D + d) = kv_keep[2 * f];
+        *(bf16x4*)(drow + 2 * D + d) = kv_keep[2 * f + 1];
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < C::NFRAG; ++f) asm volatile("" ::"v"(q_prev[f]));  // last use of the previous item's dQ data
+  }
+  {
+    const int q = wave * 16 + i16;
+    bf16x8 qf[C::KSTEPS], dqo[C::KSTEPS];
+#pragma unroll
+    for (int ks = 0; ks < C::KSTEPS; ++ks) {
+      qf[ks] = sp_frag_rows<HD>(Qs, q, ks, g);
+      dqo[ks] = sp_frag_rows<HD>(dOs, q, ks, g);
+    }
+    const float my_lse = lse_s[q], dl = del_s[q];
+    f32x4 dq[C::NFRAG];
+#pragma unroll
+    for (int f = 0; f < C::NFRAG; ++f) dq[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kb = 0; kb < L; kb += 64) {
+      f32x4 ds[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < C::KSTEPS; ++ks) {
+          s = mfma16(sp_frag_rows<HD>(Ks, kb + 16 * f + i16, ks, g), qf[ks], s);
+          dp = mfma16(sp_frag_rows<HD>(Vs, kb + 16 * f + i16, ks, g), dqo[ks], dp);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = (kb + 16 * f + 4 * g + r < Lv) ? fast_exp2(s[r] * scale_log2e - my_lse) : 0.f;
+          ds[f][r] = pv * (dp[r] - dl) * scale;
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 dsf = pack_pair(ds[2 * ks], ds[2 * ks + 1]);
+#pragma unroll
+        for (int f = 0; f < C::NFRAG; ++f) dq[f] = mfma16(sp_frag_cols<HD>(Ks, kb + 32 * ks, f, i16, g), dsf, dq[f]);
+      }
+    }
+    bf16* drow = dbase + (long)q * ld;
+#pragma unroll
+    for (int f = 0; f < C::NFRAG; ++f) {
+      const int d = 16 * f + 4 * g;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) q_cur[f][r] = f2bf(dq[f][r]);
+      if (d < HD) *(bf16x4*)(drow + d) = q_cur[f];
+    }
+#pragma unroll
+    for (int f = 0; f < 2 * C::NFRAG; ++f) asm volatile("" ::"v"(kv_keep[f]));  // last use of the dK / dV data
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// attn_bwd_dma_kernel: the single-pass backward for L = 128 and head widths whose 16-byte chunk count is odd (hd 72:
+// rows of 144 B are the conflict-free LDS pitch already, so a tile is ONE contiguous LDS image).  Same arithmetic as
+// attn_bwd_sp_kernel; what changes is how the next item arrives: its four tiles go HBM -> LDS by LDS-DMA into a SECOND
+// LDS buffer while the current item is computed from the first (2 x 72 KiB; one workgroup per CU), instead of through
+// 72 prefetch registers.  The register version could not keep its memory traffic under the arithmetic (measured with
+// the attn_dbg knob at B 1024: arithmetic alone 461 us, loads alone 333 us, full kernel 861 us): at 255 VGPRs hipcc
+// recycles store-data registers as prefetch targets and serialises the fetch behind the previous item's stores, and
+// the staging registers -> LDS at the top of every item waits for those stores as well.  Here a wave's vmcnt history
+// per item is [9 DMA + lse + 3 O-fragment loads][16 stores], the wait before the buffer hand-over is the counted
+// vmcnt(16) and the stores stay in flight across items.  The two buffers are separate __shared__ objects and the item
+// loop is unrolled by two, so every LDS access names its buffer statically and hipcc does not guard LDS reads of one
+// buffer with a wait for the DMA into the other.
+template <int HD>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dma_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                               const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                               float* __restrict__ delta, bf16* __restrict__ dqkv, int H,
+                                                               float scale, float scale_log2e, int Lv, int B) {
+  using C = SpCfg<HD>;
+  static_assert(C::PITCH == HD * 2, "tile rows must be contiguous in LDS (odd chunk count)");
+  constexpr int L = 128;
+  constexpr int TILE = L * C::PITCH;
+  constexpr int HALF_CH = L * C::CH / 2;  // chunks moved by one wave: 576 = 9 instructions of 64 lanes
+  static_assert(HALF_CH % 64 == 0, "a wave moves whole 1-KiB pieces");
+  constexpr int NDMA = HALF_CH / 64;
+  __shared__ __attribute__((aligned(16))) char buf0[4 * TILE];
+  __shared__ __attribute__((aligned(16))) char buf1[4 * TILE];
+  __shared__ float lse_s0[L], lse_s1[L], del_s[L];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, g = lane >> 4;
+  const int D = H * HD;
+  const long ld = 3L * D;
+  const int nitems = B * H;
+
+  // ---- LDS-DMA role of this wave: tile tw (0 Q, 1 K, 2 V, 3 dO), half hw; per instruction j the lane's byte offset
+  // inside the (sample, head) slab: chunk idx = hw * 576 + 64 j + lane -> row idx / CH, column chunk idx % CH
+  const int tw = wave >> 1, hw = wave & 1;
+  const long row_bytes = (tw < 3 ? ld : (long)D) * 2;
+  unsigned doff[NDMA];
+#pragma unroll
+  for (int j = 0; j < NDMA; ++j) {
+    const int idx = hw * HALF_CH + 64 * j + lane;
+    const int r = idx / C::CH, c = idx - r * C::CH;
+    doff[j] = (unsigned)(r * row_bytes + c * 16);
+  }
+  const int lds_off = tw * TILE + hw * HALF_CH * 16;  // + 1024 j
+  auto item_src = [&](int item) -> const char* {
+    int b, h;
+    sp_item_coords(item, B, H, b, h);
+    return tw < 3 ? (const char*)(qkv + (long)b * L * ld + h * HD + tw * D) : (const char*)(dout + (long)b * L * D + h * HD);
+  };
+
+  float lse_r = 0.f;
+  bf16x8 of0[C::KSTEPS], of1[C::KSTEPS];  // O fragments of this wave's queries for the item in buffer 0 / 1
+  bf16x4 qk0[C::NFRAG], qk1[C::NFRAG];    // packed dQ store data of the item computed from buffer 0 / 1 (see item_math)
+#pragma unroll
+  for (int f = 0; f < C::NFRAG; ++f) qk0[f] = qk1[f] = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+  const int qrow = wave * 16 + i16;        // this lane's query (phase B, delta) -- and key (phase A) -- row
+
+  // workgroup barrier that orders LDS only: __syncthreads() carries a workgroup-scope release fence, for which hipcc
+  // drains vmcnt(0) -- i.e. waits for every dQ / dK / dV store in flight
+#define ATTN_DMA_BARRIER()                                                                    \
+  {                                                                                           \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
+    __builtin_amdgcn_s_barrier();                                                             \
+    asm volatile("" ::: "memory");                                                            \
+  }
+  // ---- one item out of buffer P; the next item (if any) is put in flight into the other buffer
+#define ATTN_DMA_BODY(P, CUR, NXT, LSE_CUR, LSE_NXT, OF_CUR, OF_NXT, QK_CUR, QK_PRV)                                     \
+  {                                                                                                        \
+    int b, h;                                                                                              \
+    sp_item_coords(item, B, H, b, h);                                                                      \
+    const long bh = (long)b * H + h;                                                                       \
+    const char* Qs = CUR;                                                                                  \
+    const char* Ks = CUR + TILE;                                                                           \
+    const char* Vs = CUR + 2 * TILE;                                                                       \
+    const char* dOs = CUR + 3 * TILE;                                                                      \
+    /* my share of this item has landed (everything younger is a store of the previous item) */            \
+    asm volatile("" ::: "memory");                                                                         \
+    __builtin_amdgcn_s_waitcnt((16 & 15) | (7 << 4) | (15 << 8) | ((16 >> 4) << 14)); /* vmcnt(16) */      \
+    asm volatile("" ::: "memory");                                                                         \
+    if (tid < L) LSE_CUR[tid] = lse_r;                                                                     \
+    ATTN_DMA_BARRIER() /* B1: buffer P complete; every wave is done with the other buffer */               \
+    const int nxt = item + (int)gridDim.x;                                                                 \
+    { /* unconditional (the last item re-fetches itself into the idle buffer): a fetch inside a branch makes  \
+         hipcc merge the two vmcnt histories conservatively and wait for the DMA it has just issued */      \
+      const int fit = nxt < nitems ? nxt : item;                                                           \
+      const char* src = item_src(fit);                                                                     \
+      _Pragma("unroll") for (int j = 0; j < NDMA; ++j) glds16(src + opaque(doff[j]), NXT + lds_off + 1024 * j); \
+      int nb, nh;                                                                                          \
+      sp_item_coords(fit, B, H, nb, nh);                                                                   \
+      lse_r = lse[((long)nb * H + nh) * L + (tid & (L - 1))];                                              \
+      const bf16* orow = out + ((long)nb * L + qrow) * D + nh * HD;                                        \
+      _Pragma("unroll") for (int s2 = 0; s2 < C::KSTEPS; ++s2)                                             \
+        OF_NXT[s2] = *(const bf16x8*)(orow + min(32 * s2 + 8 * g, HD - 8));                                \
+    }                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    { /* delta = rowsum(dO * O) of this wave's queries */                                                  \
+      float dl = 0.f;                                                                                      \
+      _Pragma("unroll") for (int s2 = 0; s2 < C::KSTEPS; ++s2) {                                           \
+        const bf16x8 dof = sp_frag_rows<HD>(dOs, qrow, s2, g);                                             \
+        float part = 0.f;                                                                                  \
+        _Pragma("unroll") for (int e = 0; e < 8; ++e) part += bf2f(dof[e]) * bf2f(OF_CUR[s2][e]);          \
+        dl += (32 * s2 + 8 * g < HD) ? part : 0.f;                                                         \
+      }                                                                                                    \
+      dl = group_sum(dl);                                                                                  \
+      if (g == 0) {                                                                                        \
+        del_s[qrow] = dl;                                                                                  \
+        delta[bh * L + qrow] = dl;                                                                         \
+      }                                                                                                    \
+    }                                                                                                      \
+    ATTN_DMA_BARRIER() /* B2: delta of every query visible */                                              \
+    attn_bwd_item_math<HD>(Qs, Ks, Vs, dOs, LSE_CUR, del_s, dqkv + (long)b * L * ld + h * HD, ld, D, wave, i16, g, Lv, \
+                           scale, scale_log2e, QK_CUR, QK_PRV);                                            \
+    item = nxt;                                                                                            \
+  }
+
+  int item = blockIdx.x;
+  if (item >= nitems) return;
+  {  // prologue: first item -> buffer 0
+    const char* src = item_src(item);
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) glds16(src + opaque(doff[j]), buf0 + lds_off + 1024 * j);
+    int b, h;
+    sp_item_coords(item, B, H, b, h);
+    lse_r = lse[((long)b * H + h) * L + (tid & (L - 1))];
+    const bf16* orow = out + ((long)b * L + qrow) * D + h * HD;
+#pragma unroll
+    for (int s2 = 0; s2 < C::KSTEPS; ++s2) of0[s2] = *(const bf16x8*)(orow + min(32 * s2 + 8 * g, HD - 8));
+#pragma unroll
+    for (int s2 = 0; s2 < C::KSTEPS; ++s2) of1[s2] = of0[s2];
+  }
+  // the first item's body is peeled: entered from the prologue it has a different vmcnt history (no stores yet) and,
+  // merged with the loop's, would force vmcnt(0) on every buffer-0 item
+  ATTN_DMA_BODY(0, buf0, buf1, lse_s0, lse_s1, of0, of1, qk0, qk1)
+  while (item < nitems) {
+    ATTN_DMA_BODY(1, buf1, buf0, lse_s1, lse_s0, of1, of0, qk1, qk0)
+    if (item >= nitems) break;
+    ATTN_DMA_BODY(0, buf0, buf1, lse_s0, lse_s1, of0, of1, qk0, qk1)
+  }
+#undef ATTN_DMA_BODY
+#undef ATTN_DMA_BARRIER
 }
 
 // ------------------------------------------------------------------------------------------
@@ -912,34 +1220,41 @@ extern "C" int mdt_attn_bwd(const mdt_bf16* qkv, const mdt_bf16* out, const mdt_
   if (L_valid <= 0 || L_valid > L) L_valid = L;
   float sc = 1.0f / sqrtf((float)hd);
   float sl = sc * 1.4426950408889634f;
-  // Short sequences: dQ, dK, dV in ONE launch (attn_bwd_sp_kernel).  Measured on MI355X at the benchmarked shapes
-  // (tools/attn_bench.py): L = 128 / hd 72: 888 us vs 1091 us for the two block-loop kernels with one workgroup per CU
-  // per CU, persistent, next-item prefetch (809 us; the <= 128-VGPR two-per-CU build spills: 953 us); L = 256 / hd 32
-  // (decoder): 1059 vs 1347 us; L = 256 / hd 72 needs 150 KB of LDS and spills -- it stays on the block-loop kernels.
-  // "attn_sp": 0 = this default, 1 = block-loop kernels everywhere, 2 = single-pass wherever instantiated (OCC = 4 at L = 128).
+  // Short sequences: dQ, dK, dV in ONE launch.  Measured on MI355X at the benchmarked shapes (tools/attn_bench.py,
+  // tools/attn_ab.py): L = 128 / hd 72 (XL/2 encoder): two block-loop kernels 1050-1090 us, single-pass with one
+  // persistent workgroup per CU and register prefetch of the next item 809-900 us (the <= 128-VGPR two-per-CU build
+  // spills: 953 us), single-pass with the next item arriving by LDS-DMA into a second LDS buffer 745-753 us
+  // (attn_bwd_dma_kernel, the default); L = 256 / hd 32 (decoder): 1090 vs 1347 us; L = 256 / hd 72 needs 150 KB of
+  // LDS and spills -- it stays on the block-loop kernels.
+  // "attn_sp": 0 = this default, 1 = block-loop kernels everywhere, 2 = single-pass wherever instantiated (OCC = 4 at
+  // L = 128), 3 = the register-prefetch kernel where the LDS-DMA one would run.
   const int sp_knob = mdt_get_tuning_int(MDT_TUNE_ATTN_SP);
+  const int adbg = mdt_get_tuning_int(MDT_TUNE_ATTN_DBG);  // timing experiments only: 1 no stores, 2 no next-item fetch, 4 no dK/dV phase, 8 no dQ phase
   const bool sp_ok = L == 128 || (L == 256 && (hd == 32 || hd == 64 || hd == 72));  // (hd 80 at L = 256: 182 KB of LDS)
   if (sp_ok && sp_knob != 1 && (L == 128 || hd <= 64 || sp_knob == 2)) {
     dim3 g1(B * H);                                   // OCC = 4: one item per workgroup
     const int items = B * H;
     const int cus = attn_num_cus();
     dim3 gp(items < cus ? items : cus);              // OCC = 2: persistent, one workgroup per CU (multiple of 8: XCD affinity)
-    if (L == 128 && sp_knob == 2) {
+    if (L == 128 && hd == 72 && sp_knob != 2 && sp_knob != 3) {  // "attn_sp" = 3: the register-prefetch kernel (A/B)
+      hipLaunchKernelGGL(attn_bwd_dma_kernel<72>, gp, dim3(512), 0, (hipStream_t)stream, (const bf16*)qkv, (const bf16*)out,
+                         (const bf16*)dout, lse, delta, (bf16*)dqkv, H, sc, sl, L_valid, B);
+    } else if (L == 128 && sp_knob == 2) {
       ATTN_DISPATCH(hd, hipLaunchKernelGGL((attn_bwd_sp_kernel<HDc, 1, 4>), g1, dim3(512), 0, (hipStream_t)stream,
                                            (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, H,
-                                           sc, sl, L_valid, B));
+                                           sc, sl, L_valid, B, adbg));
     } else if (L == 128) {
       ATTN_DISPATCH(hd, hipLaunchKernelGGL((attn_bwd_sp_kernel<HDc, 1, 2>), gp, dim3(512), 0, (hipStream_t)stream,
                                            (const bf16*)qkv, (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, H,
-                                           sc, sl, L_valid, B));
+                                           sc, sl, L_valid, B, adbg));
     } else {
       switch (hd) {
         case 32: hipLaunchKernelGGL((attn_bwd_sp_kernel<32, 2, 2>), gp, dim3(512), 0, (hipStream_t)stream, (const bf16*)qkv,
-                                    (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, H, sc, sl, L_valid, B); break;
+                                    (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, H, sc, sl, L_valid, B, adbg); break;
         case 64: hipLaunchKernelGGL((attn_bwd_sp_kernel<64, 2, 2>), gp, dim3(512), 0, (hipStream_t)stream, (const bf16*)qkv,
-                                    (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, H, sc, sl, L_valid, B); break;
+                                    (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, H, sc, sl, L_valid, B, adbg); break;
         default: hipLaunchKernelGGL((attn_bwd_sp_kernel<72, 2, 2>), gp, dim3(512), 0, (hipStream_t)stream, (const bf16*)qkv,
-                                    (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, H, sc, sl, L_valid, B); break;
+                                    (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, H, sc, sl, L_valid, B, adbg); break;
       }
     }
     return mdt_check_launch("attn_bwd_sp");

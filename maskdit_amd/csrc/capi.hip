@@ -33,6 +33,7 @@ extern "C" int mdt_set_tuning(const char* key, int value) {
   if (!strcmp(key, "nt8_skip_epilogue")) { g_tuning[MDT_TUNE_NT8_SKIP_EPILOGUE] = value; return MDT_OK; }
   if (!strcmp(key, "tn8_dbg")) { g_tuning[MDT_TUNE_TN8_DBG] = value; return MDT_OK; }
   if (!strcmp(key, "ln_gate_rowwise")) { g_tuning[MDT_TUNE_LN_GATE_ROWWISE] = value; return MDT_OK; }
+  if (!strcmp(key, "attn_dbg")) { g_tuning[MDT_TUNE_ATTN_DBG] = value; return MDT_OK; }
   if (!strcmp(key, "tn8_wide")) { g_tuning[MDT_TUNE_TN8_WIDE] = value; return MDT_OK; }
   if (!strcmp(key, "nt8_trickle")) { g_tuning[MDT_TUNE_NT8_TRICKLE] = value; return MDT_OK; }
   if (!strcmp(key, "attn_sp")) { g_tuning[MDT_TUNE_ATTN_SP] = value; return MDT_OK; }

@@ -19,7 +19,7 @@ void mdt_set_error(const char* msg);
 int mdt_check_launch(const char* what);
 
 // tuning knobs (capi.hip; set through mdt_set_tuning)
-enum { MDT_TUNE_GEMM_NT_VARIANT = 0, MDT_TUNE_GEMM_TN_VARIANT = 1, MDT_TUNE_NT8_SKIP_EPILOGUE = 2, MDT_TUNE_NT8_STAGGER = 3, MDT_TUNE_NT8_GROUP_M = 4, MDT_TUNE_ATTN_QF = 5, MDT_TUNE_NT8_NF3 = 6, MDT_TUNE_NT8_MAX_CUS = 7, MDT_TUNE_ATTN_SP = 8, MDT_TUNE_NT8_TRICKLE = 9, MDT_TUNE_TN8_WIDE = 10, MDT_TUNE_TN8_DBG = 11, MDT_TUNE_LN_GATE_ROWWISE = 12, MDT_TUNE_COUNT = 16 };
+enum { MDT_TUNE_GEMM_NT_VARIANT = 0, MDT_TUNE_GEMM_TN_VARIANT = 1, MDT_TUNE_NT8_SKIP_EPILOGUE = 2, MDT_TUNE_NT8_STAGGER = 3, MDT_TUNE_NT8_GROUP_M = 4, MDT_TUNE_ATTN_QF = 5, MDT_TUNE_NT8_NF3 = 6, MDT_TUNE_NT8_MAX_CUS = 7, MDT_TUNE_ATTN_SP = 8, MDT_TUNE_NT8_TRICKLE = 9, MDT_TUNE_TN8_WIDE = 10, MDT_TUNE_TN8_DBG = 11, MDT_TUNE_LN_GATE_ROWWISE = 12, MDT_TUNE_ATTN_DBG = 13, MDT_TUNE_COUNT = 16 };
 int mdt_get_tuning_int(int key);
 
 #define MDT_REQUIRE(cond, msg)            \
@@ -30,8 +30,19 @@ int mdt_get_tuning_int(int key);
     }                                     \
   } while (0)
 
+// identity that hipcc cannot see through: keeps (uniform base) + (32-bit lane offset) address expressions in the
+// saddr + voffset form instead of one 64-bit vector address per access
+__device__ __forceinline__ unsigned opaque(unsigned v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+// 16 bytes per lane HBM / L2 -> LDS without a register round trip (LDS address = wave-uniform base + 16 * lane)
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gsrc), LDS_PTR(lds_dst), 16, 0, 0);
+}
 
 __device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
 __device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }

@@ -42,16 +42,6 @@ __device__ __forceinline__ void tile_coords(int s, int tiles_m, int tiles_n, int
   tn = in / gm;
 }
 
-// identity that hipcc cannot see through: keeps (uniform base) + (32-bit lane offset) address expressions in the
-// saddr + voffset form instead of one 64-bit vector address per access
-__device__ __forceinline__ unsigned opaque(unsigned v) {
-  asm volatile("" : "+v"(v));
-  return v;
-}
-
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
-  __builtin_amdgcn_global_load_lds(GLOBAL_PTR(gsrc), LDS_PTR(lds_dst), 16, 0, 0);
-}
 
 template <int CW> __device__ __forceinline__ void store_bf16_row(bf16* o, const float* v) {
   static_assert(CW % 4 == 0, "column group must be a multiple of 4");

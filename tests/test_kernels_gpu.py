@@ -290,8 +290,11 @@ def test_gemm_tn_asymmetric_and_edges():
 
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('B_,L,H,hd', [(2, 128, 3, 72), (2, 256, 4, 32), (1, 128, 2, 64), (1, 64, 1, 80), (1, 512, 2, 72),
-                                        (9, 128, 2, 80), (3, 256, 2, 72), (2, 256, 1, 64), (10, 128, 2, 32), (1, 256, 2, 80)])
-@pytest.mark.parametrize('sp', [0, 1, 2])  # 0: product dispatch, 1: block-loop kernels everywhere, 2: single-pass everywhere (2 WG/CU bwd build)
+                                        (9, 128, 2, 80), (3, 256, 2, 72), (2, 256, 1, 64), (10, 128, 2, 32), (1, 256, 2, 80),
+                                        (40, 128, 16, 72), (33, 128, 8, 72)])  # 640 / 264 items: 2-3 per persistent workgroup
+# 0: product dispatch (L 128 / hd 72: the LDS-DMA double-buffered backward), 1: block-loop kernels everywhere,
+# 2: single-pass everywhere (2 WG/CU bwd build), 3: register-prefetch single-pass backward instead of the LDS-DMA one
+@pytest.mark.parametrize('sp', [0, 1, 2, 3])
 def test_attention_fwd_bwd(B_, L, H, hd, sp):
     torch.manual_seed(3)
     D = H * hd
@@ -302,6 +305,8 @@ def test_attention_fwd_bwd(B_, L, H, hd, sp):
     o_ref2 = o_ref.transpose(1, 2).reshape(B_ * L, D)
     if sp and L not in (128, 256):
         pytest.skip('the knob only matters at L = 128 / 256')
+    if sp == 3 and not (L == 128 and hd == 72):
+        pytest.skip('knob 3 only differs from 0 where the LDS-DMA backward exists')
     _lib.lib().mdt_set_tuning(b'attn_sp', sp)
     try:
         out, lse = ops.attn_fwd(qkv, B_, L, H, hd)
