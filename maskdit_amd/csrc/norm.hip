@@ -12,6 +12,11 @@
 #define MAXV 5  // up to 5 float4 per lane => D <= 1280
 
 // ------------------------------------------------------------------------------------------
+// Branch-free: NVT = ceil(D / 4 / 64) float4 per lane; a lane whose quad lies beyond the row shadows the row's last
+// quad (same loads, same result, duplicate store) and is masked out of the two sums -- all loads of the row, including
+// the per-sample shift / scale vectors, are issued before the first use (with `if (c < nv)` around them hipcc waited
+// for every quad separately: 4.1 TB/s).
+template <int NVT>
 __global__ __launch_bounds__(256) void ln_modulate_fwd_kernel(const float* __restrict__ x, const float* __restrict__ shift,
                                                               const float* __restrict__ scale, int mod_ld,
                                                               int rows_per_sample, bf16* __restrict__ xn,
@@ -21,44 +26,44 @@ __global__ __launch_bounds__(256) void ln_modulate_fwd_kernel(const float* __res
   if (row >= M) return;
   const int nv = D >> 2;
   const float* xr = x + (long)row * D;
-  f32x4 v[MAXV];
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    int c = lane + 64 * i;
-    if (c < nv) {
-      v[i] = *(const f32x4*)(xr + 4 * c);
-      s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
-    }
-  }
-  const float mean = wave_sum(s) / (float)D;
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    int c = lane + 64 * i;
-    if (c < nv) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float d = v[i][e] - mean;
-        q += d * d;
-      }
-    }
-  }
-  const float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-6f);
   const long b = row / rows_per_sample;
   const float* sh = shift + b * mod_ld;
   const float* sc = scale + b * mod_ld;
+  f32x4 v[NVT], a[NVT], m[NVT];
+  int col[NVT];
+  float own[NVT];
+#pragma unroll
+  for (int i = 0; i < NVT; ++i) {
+    const int c = lane + 64 * i;
+    own[i] = c < nv ? 1.f : 0.f;
+    col[i] = 4 * min(c, nv - 1);
+    v[i] = *(const f32x4*)(xr + col[i]);
+    a[i] = *(const f32x4*)(sh + col[i]);
+    m[i] = *(const f32x4*)(sc + col[i]);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NVT; ++i) s += own[i] * (v[i][0] + v[i][1] + v[i][2] + v[i][3]);
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NVT; ++i) {
+    float qi = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = v[i][e] - mean;
+      qi += d * d;
+    }
+    q += own[i] * qi;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-6f);
   bf16* o = xn + (long)row * D;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    int c = lane + 64 * i;
-    if (c < nv) {
-      f32x4 a = *(const f32x4*)(sh + 4 * c), m = *(const f32x4*)(sc + 4 * c);
-      bf16x4 r;
+  for (int i = 0; i < NVT; ++i) {
+    bf16x4 r;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) r[e] = f2bf((v[i][e] - mean) * rstd * (1.f + m[e]) + a[e]);
-      *(bf16x4*)(o + 4 * c) = r;
-    }
+    for (int e = 0; e < 4; ++e) r[e] = f2bf((v[i][e] - mean) * rstd * (1.f + m[i][e]) + a[i][e]);
+    *(bf16x4*)(o + col[i]) = r;
   }
   if (lane == 0) {
     stats[2 * (long)row] = mean;
@@ -215,8 +220,15 @@ __global__ __launch_bounds__(256) void ln_modulate_bwd_kernel(const bf16* __rest
 // a PAIR of waves shares a row, each wave one half of the columns: 4 x 12 running sums per lane, the two row
 // statistics (sum g', sum g' xhat) are exchanged through LDS with one workgroup barrier per row.  Workgroup = 2 pairs;
 // pair p takes rows r_begin + p, + 2, ...  18 B/element in one pass instead of 14 + 8 in two.
-#define HV 3  // float4 per lane and half row => D <= 1536
-__global__ __launch_bounds__(256, 3) void ln_bwd_gate_split_kernel(
+// HV = float4 per lane and half row = ceil(D / 8 / 64): 1 (D <= 512), 2 (<= 1024), 3 (<= 1536)
+// Branch-free body: a lane whose column quad lies beyond the half row (i = 2, lanes >= 16 at D = 1152) works on the
+// LAST quad of the half row instead -- same loads, same arithmetic and therefore the same (duplicate) stores as the
+// lane that owns it -- and is masked out of the sums.  With `if (c < nvh)` around every load hipcc puts each quad into
+// its own divergent block and waits for its loads one by one; straight-line code issues them all up front.  The row
+// barrier is the bare s_barrier + lgkmcnt(0): __syncthreads() carries a release fence for which hipcc drains vmcnt(0),
+// i.e. waits for the previous row's dx / dys stores.
+template <int HV>
+__global__ __launch_bounds__(256, HV == 3 ? 2 : HV == 2 ? 3 : 4) void ln_bwd_gate_split_kernel(
     const bf16* __restrict__ dxn, const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ scale,
     int mod_ld, int rows_per_sample, int chunk, float* __restrict__ dx, int accumulate, float* __restrict__ dshift,
     float* __restrict__ dscale, int dmod_ld, int D, const bf16* __restrict__ gy, const float* __restrict__ ggate, int ggate_ld,
@@ -231,6 +243,14 @@ __global__ __launch_bounds__(256, 3) void ln_bwd_gate_split_kernel(
   const int q0 = hw * nvh;       // first float4 of this wave's half
   const float* sc = scale + (long)b * mod_ld;
   const float* gg_ = ggate + (long)b * ggate_ld;
+  int col[HV];      // element offset of this lane's quad i inside a row (clamped)
+  float own[HV];    // 1 where the lane owns the quad, 0 where it shadows the last one
+#pragma unroll
+  for (int i = 0; i < HV; ++i) {
+    const int c = lane + 64 * i;
+    own[i] = c < nvh ? 1.f : 0.f;
+    col[i] = 4 * (q0 + min(c, nvh - 1));
+  }
   f32x4 a_sh[HV], a_sc[HV], a_g[HV], a_b[HV];
 #pragma unroll
   for (int i = 0; i < HV; ++i) {
@@ -245,38 +265,37 @@ __global__ __launch_bounds__(256, 3) void ln_bwd_gate_split_kernel(
     const int r = r_begin + 2 * it + pair;
     const bool valid = r < r_end;  // wave-uniform; only the last iteration of an odd chunk has an idle pair
     const long row = (long)b * rows_per_sample + (valid ? r : r_begin);
-    float mean = 0.f, rstd = 0.f;
-    f32x4 xh[HV], gm[HV], pv[HV];
-    bf16x4 yv[HV];
+    const float live = valid ? 1.f : 0.f;  // an idle pair re-reads row r_begin and contributes / stores nothing
+    const float mean = stats[2 * row], rstd = stats[2 * row + 1];
+    const float* xr = x + row * D;
+    const bf16* gr = dxn + row * D;
+    float* dr = dx + row * D;
+    f32x4 xv[HV], sv[HV], pv[HV];
+    bf16x4 gv[HV], yv[HV];
+#pragma unroll
+    for (int i = 0; i < HV; ++i) {  // every load of the row up front (the second half's operands do not depend on the statistics)
+      xv[i] = *(const f32x4*)(xr + col[i]);
+      gv[i] = *(const bf16x4*)(gr + col[i]);
+      sv[i] = *(const f32x4*)(sc + col[i]);  // per-sample vector: L1 / L2 resident
+      pv[i] = *(const f32x4*)(dr + col[i]);
+      yv[i] = *(const bf16x4*)(gy + row * D + col[i]);
+    }
+    f32x4 xh[HV], gm[HV];
     float c1 = 0.f, c2 = 0.f;
-    if (valid) {
-      mean = stats[2 * row];
-      rstd = stats[2 * row + 1];
-      const float* xr = x + row * D;
-      const bf16* gr = dxn + row * D;
 #pragma unroll
-      for (int i = 0; i < HV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nvh) {
-          const f32x4 xv = *(const f32x4*)(xr + 4 * (q0 + c));
-          const bf16x4 gv = *(const bf16x4*)(gr + 4 * (q0 + c));
-          const f32x4 sv = *(const f32x4*)(sc + 4 * (q0 + c));  // per-sample vector: L1 / L2 resident
-          // the second half's operands do not depend on the row statistics: issue their loads now
-          pv[i] = accumulate ? *(const f32x4*)(dx + row * D + 4 * (q0 + c)) : (f32x4){0.f, 0.f, 0.f, 0.f};
-          yv[i] = *(const bf16x4*)(gy + row * D + 4 * (q0 + c));
+    for (int i = 0; i < HV; ++i) {
+      const float m = own[i] * live;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float g = bf2f(gv[e]);
-            const float h = (xv[e] - mean) * rstd;
-            a_sh[i][e] += g;
-            a_sc[i][e] += g * h;
-            const float gmod = g * (1.f + sv[e]);
-            xh[i][e] = h;
-            gm[i][e] = gmod;
-            c1 += gmod;
-            c2 += gmod * h;
-          }
-        }
+      for (int e = 0; e < 4; ++e) {
+        const float g = bf2f(gv[i][e]);
+        const float h = (xv[i][e] - mean) * rstd;
+        a_sh[i][e] += m * g;
+        a_sc[i][e] += m * (g * h);
+        const float gmod = g * (1.f + sv[i][e]);
+        xh[i][e] = h;
+        gm[i][e] = gmod;
+        c1 += m * gmod;
+        c2 += m * (gmod * h);
       }
     }
     c1 = wave_sum(c1);
@@ -285,44 +304,41 @@ __global__ __launch_bounds__(256, 3) void ln_bwd_gate_split_kernel(
       part[it & 1][pair][hw][0] = c1;
       part[it & 1][pair][hw][1] = c2;
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     c1 = (part[it & 1][pair][0][0] + part[it & 1][pair][1][0]) * invD;
     c2 = (part[it & 1][pair][0][1] + part[it & 1][pair][1][1]) * invD;
-    if (valid) {
-      float* dr = dx + row * D;
+    if (valid) {  // wave-uniform
 #pragma unroll
       for (int i = 0; i < HV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nvh) {
-          f32x4 o;
+        const f32x4 gt = *(const f32x4*)(gg_ + col[i]);
+        f32x4 o;
+        bf16x4 dy;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = pv[i][e] + rstd * (gm[i][e] - c1 - xh[i][e] * c2);
-          *(f32x4*)(dr + 4 * (q0 + c)) = o;
-          const f32x4 gt = *(const f32x4*)(gg_ + 4 * (q0 + c));
-          bf16x4 dy;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            a_g[i][e] += o[e] * bf2f(yv[i][e]);
-            dy[e] = f2bf(o[e] * gt[e]);
-            a_b[i][e] += bf2f(dy[e]);
-          }
-          *(bf16x4*)(gdys + row * D + 4 * (q0 + c)) = dy;
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (accumulate ? pv[i][e] : 0.f) + rstd * (gm[i][e] - c1 - xh[i][e] * c2);
+          dy[e] = f2bf(o[e] * gt[e]);
+          a_g[i][e] += own[i] * (o[e] * bf2f(yv[i][e]));
+          a_b[i][e] += own[i] * bf2f(dy[e]);
         }
+        *(f32x4*)(dr + col[i]) = o;                       // shadow lanes write the owner's values again
+        *(bf16x4*)(gdys + row * D + col[i]) = dy;
       }
     }
   }
   // combine the two pairs' per-column partials, one atomic per column per workgroup (two sum kinds at a time)
+  __syncthreads();
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     if (k) __syncthreads();
 #pragma unroll
     for (int i = 0; i < HV; ++i) {
-      const int c = lane + 64 * i;
-      if (c < nvh) {
+      if (lane + 64 * i < nvh) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          red[0][pair][4 * (q0 + c) + e] = k ? a_g[i][e] : a_sh[i][e];
-          red[1][pair][4 * (q0 + c) + e] = k ? a_b[i][e] : a_sc[i][e];
+          red[0][pair][col[i] + e] = k ? a_g[i][e] : a_sh[i][e];
+          red[1][pair][col[i] + e] = k ? a_b[i][e] : a_sc[i][e];
         }
       }
     }
@@ -452,8 +468,17 @@ extern "C" int mdt_ln_modulate_fwd(const float* x, const float* shift, const flo
   MDT_REQUIRE(x && shift && scale && xn && stats, "ln_modulate_fwd: null pointer");
   MDT_REQUIRE(D % 4 == 0 && D <= MAXV * 256, "ln_modulate_fwd: D must be a multiple of 4 and <= 1280");
   MDT_REQUIRE(M > 0 && rows_per_sample > 0 && M % rows_per_sample == 0, "ln_modulate_fwd: M must be B*rows_per_sample");
-  hipLaunchKernelGGL(ln_modulate_fwd_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, shift, scale,
-                     mod_ld, rows_per_sample, (bf16*)xn, stats, M, D);
+#define LN_FWD_LAUNCH(N)                                                                                          \
+  hipLaunchKernelGGL(ln_modulate_fwd_kernel<N>, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, x, shift, scale, \
+                     mod_ld, rows_per_sample, (bf16*)xn, stats, M, D)
+  switch (cdiv(D >> 2, 64)) {
+    case 1: LN_FWD_LAUNCH(1); break;
+    case 2: LN_FWD_LAUNCH(2); break;
+    case 3: LN_FWD_LAUNCH(3); break;
+    case 4: LN_FWD_LAUNCH(4); break;
+    default: LN_FWD_LAUNCH(5); break;
+  }
+#undef LN_FWD_LAUNCH
   return mdt_check_launch("ln_modulate_fwd");
 }
 
@@ -484,14 +509,19 @@ extern "C" int mdt_ln_modulate_bwd_gate(const mdt_bf16* dxn, const float* x, con
   int B = M / rows_per_sample;
   int chunk = pick_chunk(B, rows_per_sample);
   dim3 grid(B, cdiv(rows_per_sample, chunk));
-  if (D % 8 == 0 && !mdt_get_tuning_int(MDT_TUNE_LN_GATE_ROWWISE))  // knob "ln_gate_rowwise": the row-per-wave build (A/B)
-    hipLaunchKernelGGL(ln_bwd_gate_split_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dxn, x, stats,
-                       scale, mod_ld, rows_per_sample, chunk, dx, accumulate, dshift, dscale, dmod_ld, D, (const bf16*)y,
-                       gate, gate_ld, (bf16*)dys, dgate, dgate_ld, dbias);
-  else
+#define LN_SPLIT_LAUNCH(HVV)                                                                                             \
+  hipLaunchKernelGGL(ln_bwd_gate_split_kernel<HVV>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dxn, x, stats,   \
+                     scale, mod_ld, rows_per_sample, chunk, dx, accumulate, dshift, dscale, dmod_ld, D, (const bf16*)y,    \
+                     gate, gate_ld, (bf16*)dys, dgate, dgate_ld, dbias)
+  if (D % 8 == 0 && !mdt_get_tuning_int(MDT_TUNE_LN_GATE_ROWWISE)) {  // knob "ln_gate_rowwise": the row-per-wave build (A/B)
+    if (D <= 512) LN_SPLIT_LAUNCH(1);
+    else if (D <= 1024) LN_SPLIT_LAUNCH(2);
+    else LN_SPLIT_LAUNCH(3);
+  } else
     hipLaunchKernelGGL(ln_modulate_bwd_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16*)dxn, x, stats,
                        scale, mod_ld, rows_per_sample, chunk, dx, accumulate, dshift, dscale, dmod_ld, D, (const bf16*)y,
                        gate, gate_ld, (bf16*)dys, dgate, dgate_ld, dbias);
+#undef LN_SPLIT_LAUNCH
   return mdt_check_launch("ln_modulate_bwd_gate");
 }
 
