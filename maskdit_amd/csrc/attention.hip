@@ -582,11 +582,25 @@ __global__ __launch_bounds__(512) void attn_fwd_sp_kernel(const bf16* __restrict
 
   // every global load of the workgroup, then one wait
   SpRegs<HD, L> kreg, vreg;
-  sp_load<HD, L>(kreg, base + D, ld, tid);
-  sp_load<HD, L>(vreg, base + 2 * D, ld, tid);
+  // (branch-free: sp_load_nb; the contraction tail of the query fragments is zeroed by a select AFTER an unconditional,
+  // clamped load -- loads inside divergent blocks are awaited one by one)
+  sp_load_nb<HD, L>(kreg, base + D, ld, tid);
+  sp_load_nb<HD, L>(vreg, base + 2 * D, ld, tid);
   bf16x8 qf[KF][C::KSTEPS];
 #pragma unroll
-  for (int qi = 0; qi < KF; ++qi) load_frag_global<HD>(qf[qi], base + (long)(wave * 16 * KF + 16 * qi + i16) * ld, g);
+  for (int qi = 0; qi < KF; ++qi) {
+    const bf16* qrow = base + (long)(wave * 16 * KF + 16 * qi + i16) * ld;
+#pragma unroll
+    for (int s2 = 0; s2 < C::KSTEPS; ++s2) qf[qi][s2] = *(const bf16x8*)(qrow + min(32 * s2 + 8 * g, HD - 8));
+  }
+#pragma unroll
+  for (int qi = 0; qi < KF; ++qi)
+#pragma unroll
+    for (int s2 = 0; s2 < C::KSTEPS; ++s2) {
+      const bool in = 32 * s2 + 8 * g < HD;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[qi][s2][e] = in ? qf[qi][s2][e] : (bf16)0.f;
+    }
   sp_store<HD, L>(kreg, Ks, tid);
   sp_store<HD, L>(vreg, Vs, tid);
   __syncthreads();
