@@ -681,6 +681,13 @@ __device__ __forceinline__ void sp_item_coords(int item, int B, int H, int& b, i
 // i+1 -- four tiles, the O / dO rows for delta, lse -- are issued into registers right before the arithmetic of item i,
 // so the HBM round trip of every item but the first is hidden; 4 -> two workgroups per CU (<= 128 VGPRs, spills at
 // hd >= 64; measured slower: "attn_sp" = 2 selects it as an A/B knob), one item per workgroup.
+// workgroup barrier that orders LDS only
+#define SP_LDS_BARRIER()                                 \
+  {                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   \
+    __builtin_amdgcn_s_barrier();                        \
+    asm volatile("" ::: "memory");                       \
+  }
 template <int HD, int KF, int OCC>
 __global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
                                                               const bf16* __restrict__ dout, const float* __restrict__ lse,
@@ -770,7 +777,7 @@ __global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __res
   for (;;) {
     int b, h;
     sp_item_coords(item, B, H, b, h);
-    __syncthreads();
+    SP_LDS_BARRIER()  // (not __syncthreads(): its release fence makes hipcc wait for every store in flight)
     const bool has_next = OCC == 2 && item + (int)gridDim.x < nitems;
     // ---- the next item's loads fly under this item's arithmetic (persistent form only)
     if (has_next && !(dbg & 2)) fetch(item + gridDim.x);
@@ -892,7 +899,7 @@ __global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __res
       }
     }
     if (!has_next) break;  // (OCC != 2: one item per workgroup)
-    __syncthreads();       // every wave is done with the tiles before the next item overwrites them
+    SP_LDS_BARRIER()       // every wave is done with the tiles before the next item overwrites them
     item += gridDim.x;
     stage(item);
   }
