@@ -308,14 +308,14 @@ __global__ __launch_bounds__(256) void final_fwd_kernel(const float* __restrict_
 }
 
 // grid (B, chunks); 4 waves, wave per token.  Accumulates dW [O, Dd], dbias [O], dshift/dscale.
-__global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict__ dF, const float* __restrict__ x,
+__global__ __launch_bounds__(256, 2) void final_bwd_kernel(const float* __restrict__ dF, const float* __restrict__ x,
                                                         const float* __restrict__ stats, const float* __restrict__ shift,
                                                         const float* __restrict__ scale, int mod_ld,
                                                         const float* __restrict__ W, float* __restrict__ dx,
                                                         float* __restrict__ dW, float* __restrict__ dbias,
                                                         float* __restrict__ dshift, float* __restrict__ dscale,
                                                         int dmod_ld, int T, int chunk, int Dd, int C, int p) {
-  extern __shared__ float red[];  // [4 waves][(FO + 2) * Dd]
+  extern __shared__ float red[];  // [4 waves][6 * Dd]: see the reduction at the end
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x;
   const int t_begin = blockIdx.y * chunk, t_end = min(t_begin + chunk, T);
@@ -408,29 +408,39 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict_
       }
     }
   }
-  // cross-wave reduction through LDS, then atomics
-  float* mine = red + (long)wave * (FO + 2) * Dd;
+  // cross-wave reduction through LDS, then atomics -- in three passes of six of the FO + 2 per-column sums, so that
+  // the workgroup needs 48 KB of LDS instead of 144 KB (one workgroup = four waves per CU was all that fitted: 1.8 ms
+  // for a pass whose HBM traffic is worth 0.25 ms)
+  constexpr int RPP = 6;  // sums per pass
+  static_assert((FO + 2) % RPP == 0, "passes must tile the FO + 2 sums");
+  float* mine = red + (long)wave * RPP * Dd;
 #pragma unroll
-  for (int i = 0; i < FV; ++i) {
-    int c = lane + 64 * i;
-    if (c < nv) {
+  for (int pass = 0; pass < (FO + 2) / RPP; ++pass) {
+    if (pass) __syncthreads();
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+    for (int i = 0; i < FV; ++i) {
+      int c = lane + 64 * i;
+      if (c < nv) {
 #pragma unroll
-        for (int k = 0; k < FO; ++k) mine[k * Dd + 4 * c + e] = a_w[k][i][e];
-        mine[FO * Dd + 4 * c + e] = a_sh[i][e];
-        mine[(FO + 1) * Dd + 4 * c + e] = a_sc[i][e];
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int kk = 0; kk < RPP; ++kk) {
+            const int k = pass * RPP + kk;
+            mine[kk * Dd + 4 * c + e] = k < FO ? a_w[k < FO ? k : 0][i][e] : (k == FO ? a_sh[i][e] : a_sc[i][e]);
+          }
+        }
       }
     }
-  }
-  __syncthreads();
-  const int tot = (FO + 2) * Dd;
-  for (int idx = threadIdx.x; idx < tot; idx += 256) {
-    float s = red[idx] + red[tot + idx] + red[2 * tot + idx] + red[3 * tot + idx];
-    int k = idx / Dd, c = idx - k * Dd;
-    if (k < O) atomic_add_f32(dW + (long)k * Dd + c, s);
-    else if (k == FO) atomic_add_f32(dshift + (long)b * dmod_ld + c, s);
-    else if (k == FO + 1) atomic_add_f32(dscale + (long)b * dmod_ld + c, s);
+    __syncthreads();
+    const int tot = RPP * Dd;
+    for (int idx = threadIdx.x; idx < tot; idx += 256) {
+      float s4 = red[idx] + red[tot + idx] + red[2 * tot + idx] + red[3 * tot + idx];
+      int kk = idx / Dd, c = idx - kk * Dd;
+      const int k = pass * RPP + kk;
+      if (k < O) atomic_add_f32(dW + (long)k * Dd + c, s4);
+      else if (k == FO) atomic_add_f32(dshift + (long)b * dmod_ld + c, s4);
+      else if (k == FO + 1) atomic_add_f32(dscale + (long)b * dmod_ld + c, s4);
+    }
   }
   if (lane < O) atomic_add_f32(dbias + lane, a_b);
 }
@@ -529,7 +539,7 @@ extern "C" int mdt_final_bwd(const float* dF, const float* x, const float* stats
   while (B * splits < 1024 && T / (splits * 2) >= 16) splits *= 2;
   int chunk = cdiv(T, splits);
   dim3 grid(B, cdiv(T, chunk));
-  size_t lds = (size_t)4 * (FO + 2) * Dd * sizeof(float);
+  size_t lds = (size_t)4 * 6 * Dd * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute((const void*)final_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
