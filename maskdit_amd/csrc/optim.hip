@@ -18,6 +18,8 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, c
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
     f32x4 pv = *(const f32x4*)(p + 4 * i), gv = *(const f32x4*)(g + 4 * i);
     f32x4 mv = *(const f32x4*)(m + 4 * i), vv = *(const f32x4*)(v + 4 * i);
+    f32x4 ev = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (ema) ev = *(const f32x4*)(ema + 4 * i);  // (wave-uniform) all five loads in flight before the first use
     bf16x4 sh;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -34,7 +36,6 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, c
     *(f32x4*)(m + 4 * i) = mv;
     *(f32x4*)(v + 4 * i) = vv;
     if (ema) {
-      f32x4 ev = *(const f32x4*)(ema + 4 * i);
 #pragma unroll
       for (int e = 0; e < 4; ++e) ev[e] = ema_decay * ev[e] + (1.f - ema_decay) * pv[e];
       *(f32x4*)(ema + 4 * i) = ev;
