@@ -95,7 +95,9 @@ def test_vae_decode_vs_reference_fixture(golden_dir):
     e = _relmax(img, ref)
     rms = ((img.cpu() - ref).norm() / ref.norm()).item()
     print(f'VAE decode vs reference fixture (image 0): {e0:.3e} of max; vs oracle (both): {e:.3e} of max, {rms:.3e} rel L2')
-    assert e0 <= 3e-2 and e <= 3e-2 and rms <= 2e-2
+    # measured on MI355X (round 2): 9.1e-3 / 8.6e-3 of the image range, 7.4e-3 relative L2 (33 bf16-operand convolutions,
+    # fp32 accumulation); tolerances = 3x measured
+    assert e0 <= 2.7e-2 and e <= 2.7e-2 and rms <= 2.2e-2
     # batch invariance + workspace reuse: a second call with one latent gives the same image
     one = vae.decode(z[1:2])
     assert _relmax(one[0], img[1]) <= 2e-2  # other GEMM tile shapes at the smaller M: bf16 rounding flips through 33 layers (measured 6e-3)
