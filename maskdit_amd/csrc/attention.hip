@@ -1218,6 +1218,15 @@ extern "C" int mdt_attn_fwd(const mdt_bf16* qkv, mdt_bf16* out, float* lse, int 
     }
     return mdt_check_launch("attn_fwd_sp");
   }
+  // L = 512 at hd 72 (XL/2 encoder at 512 x 512: BASELINE configs[3]): K and V of one (sample, head) are 2 x 72 KiB --
+  // still one LDS image -- and the 32 score fragments of a 16-query block are 128 registers, so the same single-pass
+  // kernel applies with four query blocks per wave; every K / V byte is then read once per head instead of once per
+  // 64-query block.
+  if (L == 512 && hd == 72 && mdt_get_tuning_int(MDT_TUNE_ATTN_SP) != 1) {
+    hipLaunchKernelGGL((attn_fwd_sp_kernel<72, 4>), dim3(1, B * H), dim3(512), 0, (hipStream_t)stream, (const bf16*)qkv,
+                       (bf16*)out, lse, H, sl, L_valid);
+    return mdt_check_launch("attn_fwd_sp");
+  }
   // two query fragments per wave pay off for the narrow heads (hd <= 64: -8..-10 %); at hd 72/80 the
   // extra registers cost occupancy and the kernel is bound by its 144-byte-segment global reads anyway
   const int qf_knob = mdt_get_tuning_int(MDT_TUNE_ATTN_QF);

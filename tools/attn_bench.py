@@ -33,7 +33,7 @@ def main(iters=20):
     for B, L, H, hd in [(1024, 128, 16, 72), (1024, 256, 16, 32), (64, 512, 16, 72), (128, 256, 16, 72)]:
         qkv = (torch.randn(B * L, 3 * H * hd, device=dev) * 0.5).to(torch.bfloat16)
         for sp, name in ((1, 'block-loop'), (0, 'default'), (2, 'sp OCC=4')):
-            if sp != 1 and L not in (128, 256):
+            if sp != 1 and L not in (128, 256, 512):
                 continue
             L_.mdt_set_tuning(b'attn_sp', sp)
             out, lse = ops.attn_fwd(qkv, B, L, H, hd)
