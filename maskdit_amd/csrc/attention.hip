@@ -1179,6 +1179,217 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dma_kernel(const bf16* __rest
 }
 
 // ------------------------------------------------------------------------------------------
+// Backward for sequences too long for four resident tiles but short enough for TWO (L = 512 at hd 72: 2 x 72 KiB --
+// the XL/2 encoder at 512 x 512 latents).  Same arithmetic as the block-loop kernels attn_bwd_dq / attn_bwd_dkv, one
+// 8-wave workgroup per (sample, head): the pair of tiles the kernel streams (K, V for dQ; Q, dO for dK / dV) is staged
+// ONCE and stays in LDS, each wave walks its L / 8 rows in 16-row blocks -- no per-block barrier, every byte of the
+// streamed tiles is read once per head instead of once per 64-row block.
+template <int HD, int KF>
+__global__ __launch_bounds__(512, 2) void attn_bwd_q_res_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ out,
+                                                                 const bf16* __restrict__ dout, const float* __restrict__ lse,
+                                                                 float* __restrict__ delta, bf16* __restrict__ dqkv, int H,
+                                                                 float scale, float scale_log2e, int Lv) {
+  using C = SpCfg<HD>;
+  constexpr int L = 128 * KF;
+  constexpr int TILE = L * C::PITCH;
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE + 64];
+  char* Ks = smem;
+  char* Vs = smem + TILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  int b, h;
+  sp_block_coords(gridDim.y / H, H, b, h);
+  const long bh = (long)b * H + h;
+  const int D = H * HD;
+  const long ld = 3L * D;
+  const bf16* base = qkv + (long)b * L * ld + h * HD;
+  {
+    SpRegs<HD, L> kreg, vreg;
+    sp_load_nb<HD, L>(kreg, base + D, ld, tid);
+    sp_load_nb<HD, L>(vreg, base + 2 * D, ld, tid);
+    sp_store<HD, L>(kreg, Ks, tid);
+    sp_store<HD, L>(vreg, Vs, tid);
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int qi = 0; qi < KF; ++qi) {
+    const int q = wave * 16 * KF + 16 * qi + i16;
+    const long orow = ((long)b * L + q) * D + h * HD;
+    bf16x8 qf[C::KSTEPS], dqo[C::KSTEPS], of[C::KSTEPS];
+#pragma unroll
+    for (int s2 = 0; s2 < C::KSTEPS; ++s2) {  // unconditional clamped loads, contraction tail zeroed by a select
+      const int d = min(32 * s2 + 8 * g, HD - 8);
+      qf[s2] = *(const bf16x8*)(base + (long)q * ld + d);
+      dqo[s2] = *(const bf16x8*)(dout + orow + d);
+      of[s2] = *(const bf16x8*)(out + orow + d);
+    }
+    const float my_lse = lse[bh * L + q];
+    float dl = 0.f;
+#pragma unroll
+    for (int s2 = 0; s2 < C::KSTEPS; ++s2) {
+      const bool in = 32 * s2 + 8 * g < HD;
+      float part = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        part += bf2f(dqo[s2][e]) * bf2f(of[s2][e]);
+        qf[s2][e] = in ? qf[s2][e] : (bf16)0.f;
+        dqo[s2][e] = in ? dqo[s2][e] : (bf16)0.f;
+      }
+      dl += in ? part : 0.f;
+    }
+    dl = group_sum(dl);
+    if (g == 0) delta[bh * L + q] = dl;
+    f32x4 dq[C::NFRAG];
+#pragma unroll
+    for (int f = 0; f < C::NFRAG; ++f) dq[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kb = 0; kb < L; kb += 64) {
+      f32x4 ds[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < C::KSTEPS; ++ks) {
+          sv = mfma16(sp_frag_rows<HD>(Ks, kb + 16 * f + i16, ks, g), qf[ks], sv);
+          dp = mfma16(sp_frag_rows<HD>(Vs, kb + 16 * f + i16, ks, g), dqo[ks], dp);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = (kb + 16 * f + 4 * g + r < Lv) ? fast_exp2(sv[r] * scale_log2e - my_lse) : 0.f;
+          ds[f][r] = pv * (dp[r] - dl) * scale;
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 dsf = pack_pair(ds[2 * ks], ds[2 * ks + 1]);
+#pragma unroll
+        for (int f = 0; f < C::NFRAG; ++f) dq[f] = mfma16(sp_frag_cols<HD>(Ks, kb + 32 * ks, f, i16, g), dsf, dq[f]);
+      }
+    }
+    bf16* drow = dqkv + ((long)b * L + q) * ld + h * HD;
+#pragma unroll
+    for (int f = 0; f < C::NFRAG; ++f) {
+      const int d = 16 * f + 4 * g;
+      if (d < HD) {
+        bf16x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = f2bf(dq[f][r]);
+        *(bf16x4*)(drow + d) = v;
+      }
+    }
+  }
+}
+
+template <int HD, int KF>
+__global__ __launch_bounds__(512, 2) void attn_bwd_kv_res_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dout,
+                                                                  const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                  bf16* __restrict__ dqkv, int H, float scale,
+                                                                  float scale_log2e, int Lv) {
+  using C = SpCfg<HD>;
+  constexpr int L = 128 * KF;
+  constexpr int TILE = L * C::PITCH;
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE + 2 * L * 4 + 64];
+  char* Qs = smem;
+  char* dOs = smem + TILE;
+  float* lse_s = (float*)(smem + 2 * TILE);
+  float* del_s = lse_s + L;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  int b, h;
+  sp_block_coords(gridDim.y / H, H, b, h);
+  const long bh = (long)b * H + h;
+  const int D = H * HD;
+  const long ld = 3L * D;
+  const bf16* base = qkv + (long)b * L * ld + h * HD;
+  {
+    SpRegs<HD, L> qreg, doreg;
+    sp_load_nb<HD, L>(qreg, base, ld, tid);
+    sp_load_nb<HD, L>(doreg, dout + (long)b * L * D + h * HD, D, tid);
+    const float ls = lse[bh * L + (tid & (L - 1))], dd = delta[bh * L + (tid & (L - 1))];
+    sp_store<HD, L>(qreg, Qs, tid);
+    sp_store<HD, L>(doreg, dOs, tid);
+    if (tid < L) {
+      lse_s[tid] = ls;
+      del_s[tid] = dd;
+    }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int ki = 0; ki < KF; ++ki) {
+    const int k0 = wave * 16 * KF + 16 * ki;
+    bf16x8 kf[C::KSTEPS], vf[C::KSTEPS];
+#pragma unroll
+    for (int s2 = 0; s2 < C::KSTEPS; ++s2) {
+      const int d = min(32 * s2 + 8 * g, HD - 8);
+      kf[s2] = *(const bf16x8*)(base + (long)(k0 + i16) * ld + D + d);
+      vf[s2] = *(const bf16x8*)(base + (long)(k0 + i16) * ld + 2 * D + d);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < C::KSTEPS; ++s2) {
+      const bool in = 32 * s2 + 8 * g < HD;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        kf[s2][e] = in ? kf[s2][e] : (bf16)0.f;
+        vf[s2][e] = in ? vf[s2][e] : (bf16)0.f;
+      }
+    }
+    f32x4 dk[C::NFRAG], dv[C::NFRAG];
+#pragma unroll
+    for (int f = 0; f < C::NFRAG; ++f) {
+      dk[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dv[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool key_ok = (k0 + i16) < Lv;
+#pragma unroll 1
+    for (int qb = 0; qb < L; qb += 64) {
+      f32x4 pm[4], ds[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < C::KSTEPS; ++ks) {
+          sv = mfma16(sp_frag_rows<HD>(Qs, qb + 16 * f + i16, ks, g), kf[ks], sv);
+          dp = mfma16(sp_frag_rows<HD>(dOs, qb + 16 * f + i16, ks, g), vf[ks], dp);
+        }
+        const f32x4 ls = *(const f32x4*)(lse_s + qb + 16 * f + 4 * g);
+        const f32x4 dl = *(const f32x4*)(del_s + qb + 16 * f + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = key_ok ? fast_exp2(sv[r] * scale_log2e - ls[r]) : 0.f;
+          pm[f][r] = pv;
+          ds[f][r] = pv * (dp[r] - dl[r]) * scale;
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 pf = pack_pair(pm[2 * ks], pm[2 * ks + 1]);
+        const bf16x8 dsf = pack_pair(ds[2 * ks], ds[2 * ks + 1]);
+#pragma unroll
+        for (int f = 0; f < C::NFRAG; ++f) {
+          dv[f] = mfma16(sp_frag_cols<HD>(dOs, qb + 32 * ks, f, i16, g), pf, dv[f]);
+          dk[f] = mfma16(sp_frag_cols<HD>(Qs, qb + 32 * ks, f, i16, g), dsf, dk[f]);
+        }
+      }
+    }
+    bf16* drow = dqkv + ((long)b * L + k0 + i16) * ld + h * HD;
+#pragma unroll
+    for (int f = 0; f < C::NFRAG; ++f) {
+      const int d = 16 * f + 4 * g;
+      if (d < HD) {
+        bf16x4 a, c;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          a[r] = f2bf(dk[f][r]);
+          c[r] = f2bf(dv[f][r]);
+        }
+        *(bf16x4*)(drow + D + d) = a;
+        *(bf16x4*)(drow + 2 * D + d) = c;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 
 #define ATTN_DISPATCH(HD_, CALL) \
   switch (HD_) {                 \
@@ -1288,6 +1499,15 @@ extern "C" int mdt_attn_bwd(const mdt_bf16* qkv, const mdt_bf16* out, const mdt_
       }
     }
     return mdt_check_launch("attn_bwd_sp");
+  }
+  if (L == 512 && hd == 72 && sp_knob != 1) {  // two resident tiles per (sample, head): see attn_bwd_q_res_kernel
+    hipLaunchKernelGGL((attn_bwd_q_res_kernel<72, 4>), dim3(1, B * H), dim3(512), 0, (hipStream_t)stream, (const bf16*)qkv,
+                       (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, H, sc, sl, L_valid);
+    int rc = mdt_check_launch("attn_bwd_q_res");
+    if (rc) return rc;
+    hipLaunchKernelGGL((attn_bwd_kv_res_kernel<72, 4>), dim3(1, B * H), dim3(512), 0, (hipStream_t)stream, (const bf16*)qkv,
+                       (const bf16*)dout, lse, delta, (bf16*)dqkv, H, sc, sl, L_valid);
+    return mdt_check_launch("attn_bwd_kv_res");
   }
   dim3 grid(L / 64, B * H);
   ATTN_DISPATCH(hd, hipLaunchKernelGGL(attn_bwd_dq_kernel<HDc>, grid, dim3(256), 0, (hipStream_t)stream,

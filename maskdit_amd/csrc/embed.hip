@@ -194,9 +194,21 @@ __global__ __launch_bounds__(256) void unmask_bwd_kernel(const float* __restrict
   const int r0 = blockIdx.y * 32, r1 = min(r0 + 32, T);
   for (int cq = threadIdx.x; cq * 4 < Dd; cq += 256) {
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int r = r0; r < r1; ++r) {
-      int j = shuffle ? shuffle[(long)b * ids_ld + r] : r;
-      f32x4 g = *(const f32x4*)(dout + ((long)b * T + j) * Dd + 4 * cq);
+    for (int rb = r0; rb < r1; rb += 8) {
+      // eight gathered rows in flight per lane (one dependent load per iteration ran at 1.4 TB/s); rows past the
+      // chunk re-read its last row and are skipped below
+      f32x4 gq[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int rr = min(rb + u, r1 - 1);
+        const int j = shuffle ? shuffle[(long)b * ids_ld + rr] : rr;
+        gq[u] = *(const f32x4*)(dout + ((long)b * T + j) * Dd + 4 * cq);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+      const int r = rb + u;
+      if (r >= r1) break;
+      const f32x4 g = gq[u];
       if (r < L) {
         bf16x4 o;
 #pragma unroll
@@ -210,6 +222,7 @@ __global__ __launch_bounds__(256) void unmask_bwd_kernel(const float* __restrict
           for (int e = 0; e < 4; ++e) z[e] = (bf16)0.f;
           *(bf16x4*)(dxdec + ((long)b * Lp + r) * Dd + 4 * cq) = z;
         }
+      }
       }
     }
     if (dmask_token && r1 > L) {
