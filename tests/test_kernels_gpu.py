@@ -326,7 +326,7 @@ def test_attention_fwd_bwd(B_, L, H, hd, sp):
 
 
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('B_,L,D', [(3, 128, 1152), (2, 64, 512), (5, 16, 384)])
+@pytest.mark.parametrize('B_,L,D', [(3, 128, 1152), (2, 64, 512), (5, 16, 384), (2, 32, 256), (2, 32, 768), (3, 16, 1024)])  # 1..5 quads per lane
 def test_ln_modulate_fwd_bwd(B_, L, D):
     torch.manual_seed(4)
     M = B_ * L
@@ -377,7 +377,7 @@ def test_attention_padded_keys(L, Lv, hd):
     assert float(d[:, Lv:].abs().max()) == 0.0, 'padding rows must receive exactly zero gradient'
 
 
-@pytest.mark.parametrize('B_,L,D,rowwise', [(3, 128, 1152, 0), (3, 128, 1152, 1), (2, 256, 512, 0), (5, 37, 384, 0)])
+@pytest.mark.parametrize('B_,L,D,rowwise', [(3, 128, 1152, 0), (3, 128, 1152, 1), (2, 256, 512, 0), (5, 37, 384, 0), (2, 64, 1024, 0), (2, 33, 768, 0)])
 def test_ln_modulate_bwd_gate_fused(B_, L, D, rowwise):
     """LayerNorm-modulate backward fused with the backward of the residual gate that fed it ==
     mdt_ln_modulate_bwd followed by mdt_gate_bwd on the updated dx.  rowwise = 0: the column-split kernel (a pair of
