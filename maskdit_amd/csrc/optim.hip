@@ -15,32 +15,47 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, c
                                                         float inv_bc1, float inv_sqrt_bc2, float ema_decay,
                                                         float gscale) {
   const long stride = (long)gridDim.x * blockDim.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
-    f32x4 pv = *(const f32x4*)(p + 4 * i), gv = *(const f32x4*)(g + 4 * i);
-    f32x4 mv = *(const f32x4*)(m + 4 * i), vv = *(const f32x4*)(v + 4 * i);
-    f32x4 ev = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (ema) ev = *(const f32x4*)(ema + 4 * i);  // (wave-uniform) all five loads in flight before the first use
-    bf16x4 sh;
+  // two float4 per array and iteration: ten 16-byte loads in flight per lane before the first use
+  for (long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += 2 * stride) {
+    const long i1 = i0 + stride;
+    const bool two = i1 < n4;
+    const long ix[2] = {i0, two ? i1 : i0};
+    f32x4 pv[2], gv[2], mv[2], vv[2], ev[2];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float gg = gv[e] * gscale;
-      float pp = pv[e] * (1.f - lr * wd);
-      float mm = b1 * mv[e] + (1.f - b1) * gg;
-      float v2 = b2 * vv[e] + (1.f - b2) * gg * gg;
-      float denom = sqrtf(v2) * inv_sqrt_bc2 + eps;
-      pp -= (lr * inv_bc1) * (mm / denom);
-      pv[e] = pp; mv[e] = mm; vv[e] = v2;
-      sh[e] = f2bf(pp);
+    for (int u = 0; u < 2; ++u) {
+      pv[u] = *(const f32x4*)(p + 4 * ix[u]);
+      gv[u] = *(const f32x4*)(g + 4 * ix[u]);
+      mv[u] = *(const f32x4*)(m + 4 * ix[u]);
+      vv[u] = *(const f32x4*)(v + 4 * ix[u]);
+      ev[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (ema) ev[u] = *(const f32x4*)(ema + 4 * ix[u]);  // (wave-uniform)
     }
-    *(f32x4*)(p + 4 * i) = pv;
-    *(f32x4*)(m + 4 * i) = mv;
-    *(f32x4*)(v + 4 * i) = vv;
-    if (ema) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) ev[e] = ema_decay * ev[e] + (1.f - ema_decay) * pv[e];
-      *(f32x4*)(ema + 4 * i) = ev;
+    for (int u = 0; u < 2; ++u) {
+      if (u == 1 && !two) break;
+      bf16x4 sh;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float gg = gv[u][e] * gscale;
+        float pp = pv[u][e] * (1.f - lr * wd);
+        float mm = b1 * mv[u][e] + (1.f - b1) * gg;
+        float v2 = b2 * vv[u][e] + (1.f - b2) * gg * gg;
+        float denom = sqrtf(v2) * inv_sqrt_bc2 + eps;
+        pp -= (lr * inv_bc1) * (mm / denom);
+        pv[u][e] = pp; mv[u][e] = mm; vv[u][e] = v2;
+        sh[e] = f2bf(pp);
+      }
+      const long i = ix[u];
+      *(f32x4*)(p + 4 * i) = pv[u];
+      *(f32x4*)(m + 4 * i) = mv[u];
+      *(f32x4*)(v + 4 * i) = vv[u];
+      if (ema) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ev[u][e] = ema_decay * ev[u][e] + (1.f - ema_decay) * pv[u][e];
+        *(f32x4*)(ema + 4 * i) = ev[u];
+      }
+      if (w16) *(bf16x4*)(w16 + 4 * i) = sh;
     }
-    if (w16) *(bf16x4*)(w16 + 4 * i) = sh;
   }
   // tail (n % 4)
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
