@@ -81,6 +81,9 @@ typedef struct {
   float* C; int ldc;
   int n1_valid, n2_valid;
   int splits; /* 0 = auto */
+  float* colsum_a; /* optional [N1] fp32: colsum_a[n] += sum_m A[m, n] -- the bias gradient of the layer whose weight
+                      gradient this is (A = its output gradient), taken from the tiles the GEMM streams through LDS
+                      anyway instead of a separate pass over A (mdt_colsum_bf16) */
 } mdt_gemm_tn_args;
 int mdt_gemm_tn(const mdt_gemm_tn_args* a, mdt_stream_t stream);
 

@@ -30,7 +30,7 @@ class GemmNTArgs(C.Structure):
 
 class GemmTNArgs(C.Structure):
     _fields_ = [('A', vp), ('lda', i32), ('B', vp), ('ldb', i32), ('M', i32), ('N1', i32), ('N2', i32),
-                ('C', vp), ('ldc', i32), ('n1_valid', i32), ('n2_valid', i32), ('splits', i32)]
+                ('C', vp), ('ldc', i32), ('n1_valid', i32), ('n2_valid', i32), ('splits', i32), ('colsum_a', vp)]
 
 
 # name -> argtypes (the trailing stream argument is added to every compute entry)

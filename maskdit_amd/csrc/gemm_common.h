@@ -184,4 +184,4 @@ int launch_gemm_nt8(const NTParams& p, int nf, int wr, hipStream_t stream);
 int nt8_num_cus();
 int nt8_max_nf(int epi);
 int launch_gemm_tn8(const bf16* A, int lda, const bf16* B, int ldb, int M, int N1, int N2, float* C, int ldc,
-                    hipStream_t stream);
+                    hipStream_t stream, float* colsum_a = nullptr, int* colsum_done = nullptr);

@@ -47,6 +47,7 @@ struct TN8Params {
   int slots_total;     // contraction rows / 32
   int slots_per_split;
   int tiles_x, tiles_y;
+  float* colsum_x;     // optional [NX]: += column sums of X over this launch's rows (see the kernel)
   int dbg;             // timing experiments only (knob tn8_dbg): 1 = no slot refills, 2 = no fragment reads, 4 = refills re-read the first slots
 };
 
@@ -138,6 +139,34 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TN8Params p) {
   // tn8_dbg): MFMAs + barriers alone 828 us, + transpose reads 871, + refills from cache-resident rows 1020, + refills
   // of the real stream (HBM latency) 1165.
   const bool late = wave >= 4;
+  // ---- optional column sums of X (the bias gradient of the layer whose weight gradient this is): the 32 x 256 X slot
+  // of every phase is in LDS anyway.  The tiles_y workgroups that share an X tile split its 32 16-byte column chunks
+  // between them; thread (row = tid >> 4, c = tid & 15) reads chunk c_begin + c of slot row `row` -- one ds_read_b128 per
+  // phase in the same half (and under the same lgkmcnt(0)) as the transpose reads of that slot, consumed in the MFMA half.
+  const bool do_cs = p.colsum_x != nullptr;
+  const int cs_begin = ty * 32 / p.tiles_y, cs_n = (ty + 1) * 32 / p.tiles_y - cs_begin;
+  const int cs_row = tid >> 4, cs_c = tid & 15;
+  const bool cs_on = do_cs && cs_c < cs_n;
+  const int cs_chunk = cs_begin + (cs_c < cs_n ? cs_c : 0);  // 0..31 inside the 256-column X tile
+  const unsigned cs_addr = (unsigned)(size_t)LDS_PTR(smem) + (cs_chunk >> 4) * 8192 + cs_row * 256 +
+                           (((cs_chunk & 15) ^ tn8_swz(cs_row)) << 4);
+  float cs_acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cs_acc[e] = 0.f;
+  bf16x8 cs_v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) cs_v[e] = (bf16)0.f;
+#define TN8_CS_READ(slot)                                                                                   \
+  if (do_cs) {                                                                                              \
+    uint4 raw;                                                                                              \
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(raw) : "v"(cs_addr + ((slot) / 3) * 3 * SLOT_BYTES), \
+                 "n"(((slot) % 3) * SLOT_BYTES));                                                           \
+    cs_v = __builtin_bit_cast(bf16x8, raw);                                                                 \
+  }
+#define TN8_CS_ADD()                                                                                        \
+  if (cs_on) {                                                                                              \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) cs_acc[e] += bf2f(cs_v[e]);                               \
+  }
 #define TN8_WAIT_PHASE()                                          \
   {                                                               \
     if (late) tn8_wait<3 * (NSLOT - 3)>();                        \
@@ -202,8 +231,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TN8Params p) {
   TN8_WAIT_SLOTS(NSLOT - 3)
   TN8_BARRIER()
   TN8_LOAD(0, 0)
+  TN8_CS_READ(0)
   tn8_wait<63>();  // lgkmcnt(0): every wave's reads of slot 0 retired before it is refilled
   TN8_BARRIER()
+  TN8_CS_ADD()
   if (late) TN8_BARRIER()
 
   // one phase; K is a literal so that ring slot, register set and instruction offsets are static
@@ -214,7 +245,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TN8Params p) {
       const bool do_reads = ph + 1 < S && !(p.dbg & 2), do_dma = ph + NSLOT < S && !(p.dbg & 1);                                      \
       {                                                                                                 \
         /* half A (1) fragments of the next phase */                                                    \
-        if (do_reads) TN8_LOAD(((K) + 1) & 1, ((K) + 1) % NSLOT)                                        \
+        if (do_reads) {                                                                                 \
+          TN8_LOAD(((K) + 1) & 1, ((K) + 1) % NSLOT)                                                    \
+          TN8_CS_READ(((K) + 1) % NSLOT)                                                                \
+        }                                                                                               \
         /* (2) slot K was read during the previous phase: refill it with the rows of phase ph+NSLOT */  \
         if (do_dma) issue((K) % NSLOT, ph + NSLOT);                                                     \
         tn8_wait<63>(); /* lgkmcnt(0): the other group refills the slot just read in ITS next half A */ \
@@ -224,6 +258,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TN8Params p) {
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                   \
         _Pragma("unroll") for (int j = 0; j < YF; ++j) TN8_MFMA((K) & 1, i, j)                          \
         __builtin_amdgcn_s_setprio(0);                                                                  \
+        if (do_reads) TN8_CS_ADD() /* the X chunk of slot ph + 1 read in half A (landed: lgkmcnt(0) + barrier) */ \
         /* (4) publish this wave's share of the slot read two (early group) / three (late group) halves on */ \
         if (ph + NSLOT + 1 <= S) TN8_WAIT_PHASE()                                                       \
         else tn8_wait<0>();                                                                             \
@@ -242,6 +277,26 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TN8Params p) {
 #undef TN8_WAIT_SLOTS
 #undef TN8_WAIT_PHASE
 #undef TN8_BARRIER
+
+  if (do_cs) {  // the ring is dead: 32 row partials per chunk column -> LDS -> one atomic per column
+    float* red = (float*)smem;  // [32 rows][16 chunk slots][8]
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(cs_row * 16 + cs_c) * 8 + e] = cs_acc[e];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (tid < cs_n * 8) {
+      float sum = 0.f;
+      for (int r = 0; r < 32; ++r) sum += red[(r * 16 + (tid >> 3)) * 8 + (tid & 7)];
+      const int col = x0 + (cs_begin + (tid >> 3)) * 8 + (tid & 7);
+      if (col < p.NX) atomic_add_f32(p.colsum_x + col, sum);
+    }
+  }
+#undef TN8_CS_READ
+#undef TN8_CS_ADD
 
   // ---- epilogue: fp32 atomics.  MFMA C layout: col = lane&15 (second operand's index), row =
   // 4*(lane>>4) + r (first operand's index); either way the 16 lanes of a group hit 64 contiguous bytes.
@@ -265,8 +320,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TN8Params p) {
     }
 }
 
+// colsum_a (optional): column sums of A.  Folded into the kernel when A takes the X role; returns 1 in *colsum_done then.
 int launch_gemm_tn8(const bf16* A, int lda, const bf16* B, int ldb, int M, int N1, int N2, float* C, int ldc,
-                    hipStream_t stream) {
+                    hipStream_t stream, float* colsum_a, int* colsum_done) {
   TN8Params p;
   // Role assignment.  The 192-wide Y tile (YF = 6) wins whenever one width divides by 192: among the legal
   // assignments take the one that wastes the fewest MFMAs on the ragged 256-wide X tile; otherwise the 256 x 128 shape
@@ -285,6 +341,8 @@ int launch_gemm_tn8(const bf16* A, int lda, const bf16* B, int ldb, int M, int N
   if (a_is_x) { p.X = A; p.ldx = lda; p.NX = N1; p.Y = B; p.ldy = ldb; p.NY = N2; p.swap = 0; }
   else { p.X = B; p.ldx = ldb; p.NX = N2; p.Y = A; p.ldy = lda; p.NY = N1; p.swap = 1; }
   p.C = C; p.ldc = ldc;
+  p.colsum_x = (colsum_a && a_is_x) ? colsum_a : nullptr;
+  if (colsum_done) *colsum_done = p.colsum_x != nullptr;
   p.dbg = mdt_get_tuning_int(MDT_TUNE_TN8_DBG);
   const int nslot = yf == 6 ? TN8Cfg<6>::NSLOT : TN8Cfg<4>::NSLOT;
   p.tiles_x = (p.NX + 255) / 256;

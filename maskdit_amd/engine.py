@@ -51,6 +51,7 @@ LIVE_ENGINES: 'weakref.WeakSet' = weakref.WeakSet()  # lets the optimizer map a 
 # build was 4x slower (3017 us).  MDT_FUSE_LN_GATE=0 selects the two separate kernels (A/B runs).
 FUSE_LN_GATE = os.environ.get('MDT_FUSE_LN_GATE', '1') != '0'
 ADA_GROUP = 7  # encoder blocks per adaLN weight-gradient group (XL/2: 4 groups of 7 + the decoder-side group)
+FUSE_QKV_COLSUM = os.environ.get('MDT_FUSE_QKV_COLSUM', '1') != '0'  # qkv bias gradient out of the qkv weight-gradient GEMM (A/B switch)
 FUSE_COLSUM = os.environ.get('MDT_FUSE_COLSUM', '1') != '0'  # fc1 bias gradient out of the DGELU epilogue (A/B switch)
 
 
@@ -341,10 +342,11 @@ def _nt(A, lda, Bw, ldb, M, N, K, bias=0, epi=EPI_BF16, out=0, ldo=0, out2=0, ld
     return a
 
 
-def _tn(A, lda, Bm, ldb, M, N1, N2, Cc, ldc, n1v=0, n2v=0, splits=0):
+def _tn(A, lda, Bm, ldb, M, N1, N2, Cc, ldc, n1v=0, n2v=0, splits=0, colsum_a=0):
     a = GemmTNArgs()
     a.A, a.lda, a.B, a.ldb, a.M, a.N1, a.N2 = A, lda, Bm, ldb, M, N1, N2
     a.C, a.ldc, a.n1_valid, a.n2_valid, a.splits = Cc, ldc, n1v, n2v, splits
+    a.colsum_a = colsum_a or None
     return a
 
 
@@ -675,8 +677,12 @@ class PassPlan:
         g.add('mdt_gemm_tn', C.byref(K(_tn(dys, W, ao.data_ptr(), W, M, W, W, Gn('attn.proj.weight'), W))))
         g.add('mdt_gemm_nt', C.byref(K(_nt(dys, W, WT('attn.proj.weight'), W, M, W, W, epi=EPI_BF16, out=dao, ldo=W))))
         g.add('mdt_attn_bwd', qkv.data_ptr(), ao.data_ptr(), dao, lse.data_ptr(), delta, dqkv, B, rows, heads, hd, lvalid)
-        g.add('mdt_gemm_tn', C.byref(K(_tn(dqkv, 3 * W, xn1.data_ptr(), W, M, 3 * W, W, Gn('attn.qkv.weight'), W))))
-        g.add('mdt_colsum_bf16', dqkv, 3 * W, Gn('attn.qkv.bias'), M, 3 * W)
+        # the qkv bias gradient (column sums of dqkv) comes out of the weight-gradient GEMM, which streams dqkv through
+        # LDS anyway (mdt_gemm_tn_args.colsum_a): one pass over dqkv less per block
+        g.add('mdt_gemm_tn', C.byref(K(_tn(dqkv, 3 * W, xn1.data_ptr(), W, M, 3 * W, W, Gn('attn.qkv.weight'), W,
+                                          colsum_a=Gn('attn.qkv.bias') if FUSE_QKV_COLSUM else 0))))
+        if not FUSE_QKV_COLSUM:
+            g.add('mdt_colsum_bf16', dqkv, 3 * W, Gn('attn.qkv.bias'), M, 3 * W)
         g.add('mdt_gemm_nt', C.byref(K(_nt(dqkv, 3 * W, WT('attn.qkv.weight'), 3 * W, M, W, 3 * W, epi=EPI_BF16, out=dxn, ldo=W))))
         if fuse_next is not None:
             g.add('mdt_ln_modulate_bwd_gate', dxn, x_in.data_ptr(), st1.data_ptr(), sc1, NM, rows, dxp, 1, dsh1, dsc1, NM, M, W,

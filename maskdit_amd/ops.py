@@ -55,14 +55,15 @@ def gemm_nt(A, Bw, bias=None, epi=EPI_BF16, out=None, out2=None, outf=None, res=
     return out, out2, outf
 
 
-def gemm_tn(A, Bm, Cout, n1_valid=0, n2_valid=0, splits=0, N1=None, N2=None):
-    """Cout[N1,N2] += A[M,N1]^T @ Bm[M,N2] (f32 atomics)."""
+def gemm_tn(A, Bm, Cout, n1_valid=0, n2_valid=0, splits=0, N1=None, N2=None, colsum_a=None):
+    """Cout[N1,N2] += A[M,N1]^T @ Bm[M,N2] (f32 atomics); colsum_a[N1] += column sums of A (optional)."""
     _need(A, torch.bfloat16, 'A')
     _need(Bm, torch.bfloat16, 'B')
     a = GemmTNArgs()
     a.A, a.lda, a.B, a.ldb = p(A), A.stride(0), p(Bm), Bm.stride(0)
     a.M, a.N1, a.N2 = A.shape[0], (N1 or A.shape[1]), (N2 or Bm.shape[1])
     a.C, a.ldc, a.n1_valid, a.n2_valid, a.splits = p(Cout), Cout.stride(0), n1_valid, n2_valid, splits
+    a.colsum_a = p(colsum_a) if colsum_a is not None else None
     call('mdt_gemm_tn', C.byref(a), stream_ptr())
     return Cout
 

@@ -166,6 +166,13 @@ def test_gemm_tn8_pipelined(M, N1, N2):
     close(got[0, 0], ref, 1e-5, f'gemm_tn8 {M}x{N1}x{N2}')
     close(got[0, 1], ref, 1e-5, f'gemm_tn8 256x128 only {M}x{N1}x{N2}')
     close(got[0, 0], got[1, 0], 1e-5, 'gemm_tn8 vs 128x128 kernel')
+    # column sums of A out of the same launch (fused where A takes the 256-wide role of the 256x192 kernel, a separate
+    # pass otherwise -- same result either way), accumulated onto the existing contents
+    cs = torch.full((N1,), 0.5, device=DEV)
+    Cc = torch.ones(N1, N2, device=DEV)
+    ops.gemm_tn(A, Bm, Cc, colsum_a=cs)
+    close(Cc, ref, 1e-5, f'gemm_tn8 with column sums {M}x{N1}x{N2}')
+    close(cs, A.float().sum(0) + 0.5, 1e-5, 'column sums of A')
     # asymmetric operand: A^T picks rows of B (detects transposed / permuted stores)
     A2 = torch.zeros(M, N1, device=DEV)
     A2[torch.arange(N1), torch.arange(N1)] = 1.0
