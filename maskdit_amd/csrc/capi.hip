@@ -29,6 +29,7 @@ extern "C" int mdt_set_tuning(const char* key, int value) {
   if (!strcmp(key, "gemm_nt_variant")) { g_tuning[MDT_TUNE_GEMM_NT_VARIANT] = value; return MDT_OK; }
   if (!strcmp(key, "attn_qf")) { g_tuning[MDT_TUNE_ATTN_QF] = value; return MDT_OK; }
   if (!strcmp(key, "nt8_group_m")) { g_tuning[MDT_TUNE_NT8_GROUP_M] = value; return MDT_OK; }
+  if (!strcmp(key, "nt8_sched")) { g_tuning[MDT_TUNE_NT8_SCHED] = value; return MDT_OK; }
   if (!strcmp(key, "nt8_stagger")) { g_tuning[MDT_TUNE_NT8_STAGGER] = value; return MDT_OK; }
   if (!strcmp(key, "nt8_skip_epilogue")) { g_tuning[MDT_TUNE_NT8_SKIP_EPILOGUE] = value; return MDT_OK; }
   if (!strcmp(key, "tn8_dbg")) { g_tuning[MDT_TUNE_TN8_DBG] = value; return MDT_OK; }

@@ -19,7 +19,7 @@ void mdt_set_error(const char* msg);
 int mdt_check_launch(const char* what);
 
 // tuning knobs (capi.hip; set through mdt_set_tuning)
-enum { MDT_TUNE_GEMM_NT_VARIANT = 0, MDT_TUNE_GEMM_TN_VARIANT = 1, MDT_TUNE_NT8_SKIP_EPILOGUE = 2, MDT_TUNE_NT8_STAGGER = 3, MDT_TUNE_NT8_GROUP_M = 4, MDT_TUNE_ATTN_QF = 5, MDT_TUNE_NT8_NF3 = 6, MDT_TUNE_NT8_MAX_CUS = 7, MDT_TUNE_ATTN_SP = 8, MDT_TUNE_NT8_TRICKLE = 9, MDT_TUNE_TN8_WIDE = 10, MDT_TUNE_TN8_DBG = 11, MDT_TUNE_LN_GATE_ROWWISE = 12, MDT_TUNE_ATTN_DBG = 13, MDT_TUNE_COUNT = 16 };
+enum { MDT_TUNE_GEMM_NT_VARIANT = 0, MDT_TUNE_GEMM_TN_VARIANT = 1, MDT_TUNE_NT8_SKIP_EPILOGUE = 2, MDT_TUNE_NT8_STAGGER = 3, MDT_TUNE_NT8_GROUP_M = 4, MDT_TUNE_ATTN_QF = 5, MDT_TUNE_NT8_NF3 = 6, MDT_TUNE_NT8_MAX_CUS = 7, MDT_TUNE_ATTN_SP = 8, MDT_TUNE_NT8_TRICKLE = 9, MDT_TUNE_TN8_WIDE = 10, MDT_TUNE_TN8_DBG = 11, MDT_TUNE_LN_GATE_ROWWISE = 12, MDT_TUNE_ATTN_DBG = 13, MDT_TUNE_NT8_SCHED = 14, MDT_TUNE_COUNT = 16 };
 int mdt_get_tuning_int(int key);
 
 #define MDT_REQUIRE(cond, msg)            \
@@ -35,6 +35,12 @@ int mdt_get_tuning_int(int key);
 __device__ __forceinline__ unsigned opaque(unsigned v) {
   asm volatile("" : "+v"(v));
   return v;
+}
+
+// the same for a wave-uniform pointer: pins it in a scalar register pair
+__device__ __forceinline__ const char* sopaque(const char* p) {
+  asm volatile("" : "+s"(p));
+  return p;
 }
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))

@@ -9,8 +9,10 @@
 //     in phase p (exactly one LDS-DMA instruction per wave), B = NF instructions per wave.
 //     A slot is refilled with K-tile t+2 in the phase right after its last ds_read retired, so
 //     every load has ~6 phases (1.5 K-tiles of MFMA work) to land;
-//   * phase g: [ds_read the fragments of phase g+1 into the alternate register set]
-//              [LDS-DMA refill of the slot read during phase g-1]  [4*NF MFMAs of phase g]
+//   * phase g: the 4*NF MFMAs of phase g with ONE memory instruction pinned behind each of the first ones
+//              (sched_barrier): the ds_reads of phase g+1's fragments into the alternate register set, then the
+//              LDS-DMA refill of the slot read during phase g-1 (round 3; round 2 clustered reads / DMA / MFMAs: both
+//              waves of a SIMD then queue memory instructions in front of an idle matrix pipe, -13 % on the K loop);
 //              s_waitcnt vmcnt(W_p) lgkmcnt(0) ; s_barrier
 //     W_p = number of loads issued after the one that the NEXT phase's reads depend on (loads
 //     retire in order), computed at compile time -- never 0 until the last two K-tiles;
@@ -30,6 +32,9 @@
 // Requirements (checked by the dispatcher in gemm.hip): M % (128*WR) == 0, N % (64*NF) == 0,
 // K % 128 == 0, 16-byte aligned rows of every output.  Everything else runs the 128x128 kernel in gemm.hip.
 #pragma once
+#ifndef NT8_DEFAULT_SCHED
+#define NT8_DEFAULT_SCHED 5  // one memory instruction behind each MFMA: +8..11 % on the K loop over the clustered form (round 3)
+#endif
 #include "common.h"
 #include "../../include/maskdit_hip.h"
 #include "gemm_common.h"
@@ -139,9 +144,23 @@ constexpr int epi_depth(int E, int NF) {
 // WR = wave rows: 2 -> 256-row tile, 8 waves, one workgroup per CU (next-tile prefetch under the
 // epilogue); 1 -> 128-row tile, 4 waves, TWO independent workgroups per CU, so one workgroup's
 // epilogue (an HBM-write burst with idle matrix cores) runs under the other's K loop.
-template <int NF, int WR, int E>
+// SCHED = placement of the LDS-DMA refills (and fragment reads) inside a phase -- see PAIR_BODY; bit 4 = the
+// round-2 addressing (per-lane 64-bit address arithmetic in the K loop) for A/B runs.
+template <int NF, int WR, int E, int SCHED = NT8_DEFAULT_SCHED>
 __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
   using namespace nt8;
+  constexpr int SP = SCHED & 15;            // placement variant
+  constexpr bool SADDR = !(SCHED & 16);     // scalar K-tile base + 32-bit lane offset (saddr-form LDS-DMA)
+  // timing decomposition of the K loop (garbage results; tools/nt8_sched.py): skip the steady-state LDS-DMA refills /
+  // the fragment reads / the phase barriers
+  // fine-interleave (NT8_FINE) parameters: fragment-read stride, MFMA index behind which the A / B pieces of the
+  // LDS-DMA refill are issued, j-major last half-phase for the single-buffered B of NF = 4
+  constexpr int RS = SP == 9 ? 2 : 1;
+  constexpr int QLAST = 4 * NF - 1;
+  constexpr int QA = SP == 8 ? QLAST : SP == 9 ? (9 < QLAST ? 9 : QLAST) : 4;
+  constexpr int QB = SP == 8 ? QLAST : SP == 9 ? QLAST : (8 < QLAST ? 8 : QLAST);
+  constexpr bool FJ = NF == 4 && (SP == 5 || SP == 11);  // (measured and dropped: non-temporal epilogue stores -- the plain-bf16 epilogue gets 8-17 % SLOWER, gpurun_out/r3/sched4.log)
+  constexpr bool X_NODMA = (SCHED & 32) != 0, X_NOREAD = (SCHED & 64) != 0, X_NOBAR = (SCHED & 128) != 0;
   constexpr int BN8 = 64 * NF;
   constexpr int BM8 = 128 * WR;
   constexpr int RPP = 2 / WR;            // B LDS-DMA rounds per phase
@@ -157,6 +176,9 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
+  // the two waves of a SIMD are w and w + WAVES/2 (a workgroup's waves go round the four SIMDs): "first half"
+  // = the first wave of each SIMD
+  const bool first_half = wave < 2 * WR;
 
   const int tiles_m = p.M / BM8, tiles_n = p.N / BN8;
   const int ntiles = tiles_m * tiles_n;
@@ -186,15 +208,20 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
   const int a_lds0 = a_row0 * 128;           // + 32q*128 + stage*STAGE
   const int b_lds0 = A_BYTES + wave * 1024;  // + j*8192 + stage*STAGE
 
-  auto issue = [&](int stage, int kt, int ph) {
+  auto issue = [&](int stage, int kt, int ph, int part = 3) {  // part: 1 = the A slot, 2 = the B rounds
     char* base = smem + stage * STAGE;
     // the empty asm makes a lane offset opaque at every use: hipcc would otherwise fold it into a per-lane
-    // 64-bit base once and carry vector addresses (and their 64-bit adds) through the K loop
-    glds16(a_u + (long)kt * 128 + opaque(a_lo[ph]), base + a_lds0 + ph * 4096);
-    if (ph < NF) {
+    // 64-bit base once and carry vector addresses (and their 64-bit adds) through the K loop; the K-tile base is
+    // pinned in scalar registers the same way (otherwise the loop-invariant part of kt is re-associated to the
+    // vector side: two v_lshl_add_u64 per LDS-DMA in the round-2 ISA)
+    const char* ak = a_u + (long)kt * 128;
+    const char* bk = b_u + (long)kt * 128;
+    if (SADDR) { ak = sopaque(ak); bk = sopaque(bk); }
+    if (part & 1) glds16(ak + opaque(a_lo[ph]), base + a_lds0 + ph * 4096);
+    if ((part & 2) && ph < NF) {
 #pragma unroll
       for (int r = 0; r < RPP; ++r) {
-        glds16(b_u + (long)kt * 128 + opaque(b_lo[ph * RPP + r]), base + b_lds0 + (ph * RPP + r) * (BROWS * 128));
+        glds16(bk + opaque(b_lo[ph * RPP + r]), base + b_lds0 + (ph * RPP + r) * (BROWS * 128));
       }
     }
   };
@@ -255,6 +282,7 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
 #pragma unroll
   for (int ph = 0; ph < 4; ++ph) issue(1, 1, ph);
 
+  if (SP == 10 && !first_half) __builtin_amdgcn_s_setprio(1);  // static priority for the second wave of each SIMD
   for (;;) {  // persistent tile loop
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -278,12 +306,26 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
 
   // NOTE the operand order of the MFMA: (B fragment, A fragment) -> the accumulator holds the TRANSPOSED
   // 16x16 block: register r of lane l = C[row = l & 15][col = 4 * (l >> 4) + r].
-#define PAIR_BODY(DRAIN)                                                                              \
-  _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                            \
-    const char* cur = smem + half * STAGE;                                                            \
-    const char* nxt = smem + (half ^ 1) * STAGE;                                                      \
-    _Pragma("unroll") for (int ph = 0; ph < 4; ++ph) {                                                \
-      /* (1) prefetch the fragments of the next phase */                                              \
+  // Placement variants of a phase (SP; measured with tools/nt8_sched.py at M = 131072, K loop only, qkv forward /
+  // 4608 x 1152 (NF 4), TFLOP/s, one box: gpurun_out/r3/sched{1,2,3}.log):
+  //   0  reads + LDS-DMA at the phase start, then the MFMA cluster (round 2; 16 = with round 2's 64-bit vector
+  //      address arithmetic: 1242 / 1350)                                                                1262 / 1364
+  //   1  waves 0-3 as 0; waves 4-7 (the second wave of every SIMD) issue their LDS-DMA AFTER the cluster   (-1 %)
+  //   2  every wave issues its LDS-DMA after the cluster                                                  1362 / 1450
+  //   3  every wave issues its LDS-DMA between the ks = 0 and ks = 1 halves of the cluster                (+1..4 %)
+  //   4  waves 0-3 as 0; waves 4-7 LDS-DMA in the middle                                                  (-5 %)
+  //   5  ONE MEMORY INSTRUCTION PINNED BEHIND EACH MFMA (NT8_FINE), no setprio: THE DEFAULT               1412 / 1512
+  //   6  as 1, and waves 4-7 also issue their fragment reads in the middle of the cluster                 (-3 %)
+  //   7  as 0 without s_setprio                                                                           1316 / 1423
+  //   8 / 9 / 10  variations of 5 (LDS-DMA behind the last MFMA; reads behind every second MFMA; static s_setprio 1
+  //      for waves 4-7): all within +-1.5 % of 5
+  // In the clustered forms both waves of a SIMD queue their reads and LDS-DMA in front of an idle matrix pipe at every
+  // phase start; interleaved, each memory instruction issues in the shadow of the partner wave's MFMA.  Decomposition
+  // of 5 (SCHED bits 32 / 64 / 128, garbage results): no LDS-DMA 1615, no fragment reads 1700, no barriers 1460,
+  // neither DMA nor reads 1836, MFMAs alone 1955-2054 (= the clock-limited matrix rate): what is left is the cost of
+  // the memory instructions themselves (~14 matrix-pipe cycles per ds_read_b128, ~35 per LDS-DMA), not the barriers.
+  // The counted waits are the same for every variant: per wave the ORDER of (issue, wait) events is unchanged.
+#define NT8_READS(DRAIN)                                                                              \
       if (ph < 3) {                                                                                   \
         _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
@@ -297,13 +339,13 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
               Br[BDB ? (half ^ 1) : 0][j][ks] = *(const bf16x8*)(nxt + b_off[ks] + j * 2048);         \
           }                                                                                           \
         }                                                                                             \
-      }                                                                                               \
-      /* (2) refill the slot whose reads retired before the previous barrier */                       \
+      }
+#define NT8_DMA(DRAIN)                                                                                \
       if (!DRAIN) issue(half, kt + half + 2, ph);                                                     \
-      if (E == E_TRK && !DRAIN) trickle((kt + half) * 4 + ph, acc[2 * ph][0]);                        \
-      /* (3) this phase's MFMAs */                                                                    \
-      __builtin_amdgcn_s_setprio(1);                                                                  \
-      _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                              \
+      if (E == E_TRK && !DRAIN) trickle((kt + half) * 4 + ph, acc[2 * ph][0]);
+#define NT8_MFMAS(DRAIN, KS)                                                                          \
+      {                                                                                               \
+        constexpr int ks = KS;                                                                        \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
         _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                \
           acc[2 * ph + i][j] = mfma16(Br[BDB ? half : 0][j][ks], Ar[ph & 1][i][ks], acc[2 * ph + i][j]); \
@@ -311,8 +353,67 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
           _Pragma("unroll") for (int j = 0; j < NF; ++j)                                              \
             Br[0][j][ks] = *(const bf16x8*)(nxt + b_off[ks] + j * 2048);                              \
         }                                                                                             \
+      }
+  // SP 5: one memory instruction pinned behind every MFMA (the reads of the next phase first, the A piece of the
+  // LDS-DMA refill after MFMA 4, the B piece after MFMA 8), no s_setprio
+#define NT8_FINE(DRAIN)                                                                               \
+      _Pragma("unroll") for (int q = 0; q < 4 * NF; ++q) {                                            \
+        /* MFMA order: (ks, i, j); FJ (NF = 4, last phase): the ks = 1 half runs (j, i) so that B[j][1] dies early */ \
+        const bool jm = FJ && ph == 3 && q >= 2 * NF;                                                 \
+        const int ks = q / (2 * NF), i = jm ? (q & 1) : (q / NF) & 1, j = jm ? (q - 2 * NF) >> 1 : q % NF; \
+        acc[2 * ph + i][j] = mfma16(Br[BDB ? half : 0][j][ks], Ar[ph & 1][i][ks], acc[2 * ph + i][j]); \
+        if (X_NOREAD) {                                                                               \
+        } else if (ph < 3) {                                                                          \
+          if (q % RS == 0 && q / RS < 4) {                                                            \
+            const int r = q / RS;                                                                     \
+            Ar[(ph + 1) & 1][r & 1][r >> 1] = *(const bf16x8*)(cur + a_off[r >> 1] + (2 * (ph + 1) + (r & 1)) * 2048); \
+          }                                                                                           \
+        } else if (!(DRAIN && half == 1)) {                                                           \
+          if (q < 4) Ar[0][q & 1][q >> 1] = *(const bf16x8*)(nxt + a_off[q >> 1] + (q & 1) * 2048);   \
+          else if (BDB && q - 4 < 2 * NF)                                                             \
+            Br[BDB ? (half ^ 1) : 0][(q - 4) % NF][(q - 4) / NF] = *(const bf16x8*)(nxt + b_off[(q - 4) / NF] + ((q - 4) % NF) * 2048); \
+          else if (!BDB && !FJ && q >= 2 * NF && q - 2 * NF < NF)                                     \
+            Br[0][q - 2 * NF][0] = *(const bf16x8*)(nxt + b_off[0] + (q - 2 * NF) * 2048);            \
+          else if (!BDB && FJ && q >= NF + 1 && q <= 2 * NF)           /* B[j][0] dies at q = NF + j */ \
+            Br[0][q - NF - 1][0] = *(const bf16x8*)(nxt + b_off[0] + (q - NF - 1) * 2048);            \
+          else if (!BDB && FJ && q > 2 * NF && (q & 1))                /* B[j][1] dies at q = 2 NF + 2 j + 1 */ \
+            Br[0][(q - 2 * NF) >> 1][1] = *(const bf16x8*)(nxt + b_off[1] + ((q - 2 * NF) >> 1) * 2048); \
+        }                                                                                             \
+        if (!DRAIN && !X_NODMA && q == (ph < 3 ? QA : 3 * NF)) issue(half, kt + half + 2, ph, 1);     \
+        if (!DRAIN && !X_NODMA && q == (ph < 3 ? QB : 4 * NF - 1)) issue(half, kt + half + 2, ph, 2);  \
+        __builtin_amdgcn_sched_barrier(0);                                                            \
       }                                                                                               \
-      __builtin_amdgcn_s_setprio(0);                                                                  \
+      if (!BDB && !FJ && ph == 3 && !(DRAIN && half == 1) && !X_NOREAD) {                             \
+        _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                \
+          Br[0][j][1] = *(const bf16x8*)(nxt + b_off[1] + j * 2048);                                  \
+      }
+#define PAIR_BODY(DRAIN)                                                                              \
+  _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                            \
+    const char* cur = smem + half * STAGE;                                                            \
+    const char* nxt = smem + (half ^ 1) * STAGE;                                                      \
+    _Pragma("unroll") for (int ph = 0; ph < 4; ++ph) {                                                \
+      if (SP == 5 || SP >= 8) { NT8_FINE(DRAIN) } else {                                                         \
+      /* (1) prefetch the fragments of the next phase */                                              \
+      if (SP != 6 || first_half) { NT8_READS(DRAIN) }                                                 \
+      /* (2) refill the slot whose reads retired before the previous barrier */                       \
+      if (SP == 0 || SP == 7 || ((SP == 1 || SP == 4 || SP == 6) && first_half)) { NT8_DMA(DRAIN) } \
+      /* (3) this phase's MFMAs */                                                                    \
+      if (SP != 7) __builtin_amdgcn_s_setprio(1);                                          \
+      NT8_MFMAS(DRAIN, 0)                                                                             \
+      if (SP == 3 || (SP == 4 && !first_half)) {                                                      \
+        __builtin_amdgcn_s_setprio(0);                                                                \
+        NT8_DMA(DRAIN)                                                                                \
+        __builtin_amdgcn_s_setprio(1);                                                                \
+      }                                                                                               \
+      if (SP == 6 && !first_half) {                                                                   \
+        __builtin_amdgcn_s_setprio(0);                                                                \
+        NT8_READS(DRAIN)                                                                              \
+        __builtin_amdgcn_s_setprio(1);                                                                \
+      }                                                                                               \
+      NT8_MFMAS(DRAIN, 1)                                                                             \
+      if (SP != 7) __builtin_amdgcn_s_setprio(0);                                          \
+      if (SP == 2 || ((SP == 1 || SP == 6) && !first_half)) { NT8_DMA(DRAIN) }                        \
+      }                                                                                               \
       /* (4) publish: my share of the next phase's data has landed, my LDS reads have retired */      \
       if (DRAIN) {                                                                                    \
         if (half == 0 && ph == 0) wait_vm_lgkm<drain_count(0, NF, RPP)>();                            \
@@ -327,7 +428,7 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
       else if (ph == 1) wait_vm_lgkm<wait_count(1, NF, RPP, E == E_TRK)>();                           \
       else if (ph == 2) wait_vm_lgkm<wait_count(2, NF, RPP, E == E_TRK)>();                           \
       else wait_vm_lgkm<wait_count(3, NF, RPP, E == E_TRK)>();                                        \
-      __builtin_amdgcn_s_barrier();                                                                   \
+      if (!X_NOBAR) __builtin_amdgcn_s_barrier();                                                     \
       asm volatile("" ::: "memory");                                                                  \
     }                                                                                                 \
   }
@@ -336,6 +437,10 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
   for (; kt + 2 < nk; kt += 2) { PAIR_BODY(false) }
   { PAIR_BODY(true) }
 #undef PAIR_BODY
+#undef NT8_READS
+#undef NT8_DMA
+#undef NT8_MFMAS
+#undef NT8_FINE
 
   // ---- next tile: put its first two K-tiles in flight (every LDS read of this tile retired
   // before the last barrier), then run this tile's epilogue underneath them

@@ -341,12 +341,14 @@ int launch_gemm_tn8(const bf16* A, int lda, const bf16* B, int ldb, int M, int N
   if (a_is_x) { p.X = A; p.ldx = lda; p.NX = N1; p.Y = B; p.ldy = ldb; p.NY = N2; p.swap = 0; }
   else { p.X = B; p.ldx = ldb; p.NX = N2; p.Y = A; p.ldy = lda; p.NY = N1; p.swap = 1; }
   p.C = C; p.ldc = ldc;
-  p.colsum_x = (colsum_a && a_is_x) ? colsum_a : nullptr;
+  p.tiles_x = (p.NX + 255) / 256;
+  p.tiles_y = p.NY / (32 * yf);
+  // the fused column sums share an X tile's 256 columns out between the tiles_y workgroups of that tile, 16 chunk
+  // lanes each: with a single Y tile half of the columns would have no owner -> separate pass then
+  p.colsum_x = (colsum_a && a_is_x && p.tiles_y >= 2) ? colsum_a : nullptr;
   if (colsum_done) *colsum_done = p.colsum_x != nullptr;
   p.dbg = mdt_get_tuning_int(MDT_TUNE_TN8_DBG);
   const int nslot = yf == 6 ? TN8Cfg<6>::NSLOT : TN8Cfg<4>::NSLOT;
-  p.tiles_x = (p.NX + 255) / 256;
-  p.tiles_y = p.NY / (32 * yf);
   p.slots_total = M / 32;
   const int tiles = p.tiles_x * p.tiles_y;
   // split the contraction: minimise (waves of 256 workgroups) x (slots per split + fixed per-block cost

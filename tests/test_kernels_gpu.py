@@ -144,7 +144,8 @@ def test_gemm_tn(M, N1, N2, splits):
 
 
 @pytest.mark.parametrize('M,N1,N2', [(8192, 1152, 384), (8192, 384, 1152), (8320, 640, 512), (16384, 512, 2048),
-                                     (8192, 1152, 4608), (8384, 3456, 1152), (8192, 1536, 512), (12352, 1152, 1152)])
+                                     (8192, 1152, 4608), (8384, 3456, 1152), (8192, 1536, 512), (12352, 1152, 1152),
+                                     (8192, 2048, 128), (8192, 1024, 128)])  # a single Y tile: column sums must take the separate pass
 def test_gemm_tn8_pipelined(M, N1, N2):
     """Large weight-gradient shapes take the ring-pipelined kernel (gemm_tn8.hip) in its 256x192 shape when a width
     divides by 192 (every XL/2 encoder weight gradient) and in the 256x128 shape otherwise: ragged 256-wide tiles
@@ -219,12 +220,19 @@ def test_gemm_nt8_pipelined(M, N, K):
     try:
         for kw in cases:
             got = {}
-            for v, nf3 in ((1, 0), (2, 0), (3, 0), (2, 1)):  # 128x128; 8-wave 256-row; 4-wave 128-row (2 WG / CU); 8-wave, 192-col pref
+            # 128x128; 8-wave 256-row; 4-wave 128-row (2 WG / CU); 8-wave, 192-col pref; then the PERSISTENT multi-tile
+            # walk forced at test size (`nt8_max_cus`: 8 / 24 workgroups walk all the tiles, >= 6 tiles each at the larger
+            # shapes, with the next tile's K-tiles in flight under every epilogue class -- what the benchmarked
+            # M = 131072 launches do)
+            variants = ((1, 0, 0), (2, 0, 0), (3, 0, 0), (2, 1, 0), (2, 0, 8), (2, 1, 24), (3, 0, 8))
+            for v, nf3, cus in variants:
                 lib.mdt_set_tuning(b'gemm_nt_variant', v)
                 lib.mdt_set_tuning(b'nt8_nf3', nf3)
-                got[(v, nf3)] = run(kw)
-            for key in ((2, 0), (3, 0), (2, 1)):
-                for idx, (x, y) in enumerate(zip(got[(1, 0)], got[key])):
+                lib.mdt_set_tuning(b'nt8_max_cus', cus)
+                got[(v, nf3, cus)] = run(kw)
+            lib.mdt_set_tuning(b'nt8_max_cus', 0)
+            for key in variants[1:]:
+                for idx, (x, y) in enumerate(zip(got[(1, 0, 0)], got[key])):
                     assert (x is None) == (y is None)
                     if x is None:
                         continue
@@ -259,6 +267,89 @@ def test_gemm_nt8_pipelined(M, N, K):
     finally:
         lib.mdt_set_tuning(b'gemm_nt_variant', 0)
         lib.mdt_set_tuning(b'nt8_nf3', 0)
+        lib.mdt_set_tuning(b'nt8_max_cus', 0)
+
+
+@pytest.mark.parametrize('N1,N2,colsum', [(1152, 4608, False), (4608, 1152, False), (1152, 1152, False), (3456, 1152, True)])
+def test_gemm_tn8_production_size(N1, N2, colsum):
+    """The four XL/2 encoder weight-gradient launches AT THE BENCHMARKED SIZE (131 072 token rows = batch 1024 x 128
+    kept tokens; fc2 / fc1 / proj / qkv incl. the fused qkv-bias column sums): the split over rows, the atomics pattern
+    and the ring length differ from the 8 - 16 k-row cases of test_gemm_tn8_pipelined.  Reference: fp64 matmul of the
+    same bf16 operands (train.py:200-230's backward at configs[1])."""
+    M = 131072
+    torch.manual_seed(23)
+    A = bf(torch.randn(M, N1, device=DEV) * 0.25)
+    Bm = bf(torch.randn(M, N2, device=DEV) * 0.5)
+    Cc = torch.full((N1, N2), 0.125, device=DEV)
+    cs = torch.full((N1,), 0.5, device=DEV) if colsum else None
+    ops.gemm_tn(A, Bm, Cc, colsum_a=cs)
+    ref = torch.empty(N1, N2, device=DEV, dtype=torch.float64)
+    step = 16384
+    ref.zero_()
+    for r0 in range(0, M, step):  # fp64 in row chunks (bounded scratch)
+        ref += A[r0:r0 + step].double().t() @ Bm[r0:r0 + step].double()
+    close(Cc.double() - 0.125, ref, 2e-5, f'gemm_tn8 production size {N1}x{N2}')
+    if colsum:
+        close(cs.double() - 0.5, A.double().sum(0), 2e-5, 'fused column sums at production size')
+    # a second launch accumulates onto the first (gradient accumulation semantics) and is deterministic to fp32 atomics
+    ops.gemm_tn(A, Bm, Cc)
+    close(Cc.double() - 0.125, 2 * ref, 2e-5, 'accumulating launch')
+
+
+@pytest.mark.parametrize('N,K,case', [(4608, 1152, 'dgelu_colsum'), (1152, 4608, 'gate_res'), (1152, 1152, 'gate_res_keep_y'),
+                                      (4608, 1152, 'gelu'), (3456, 1152, 'plain'), (1152, 3456, 'plain_colsum')])
+def test_gemm_nt8_production_rows(N, K, case):
+    """Every fused epilogue class of an XL/2 encoder block at a row count where each persistent workgroup walks MANY
+    tiles (M = 32 768 rows, `nt8_max_cus` 32: 18 - 72 tiles per workgroup; the benchmark runs M = 131 072 on 256 CUs =
+    9 - 36 tiles each), against the 128x128 kernel bit for bit (same accumulation order) -- incl. E_DACT with the fused
+    column sums, which no other test runs over more than one tile per workgroup."""
+    M, L = 32768, 128
+    torch.manual_seed(24)
+    A = bf(torch.randn(M, K, device=DEV) * 0.5)
+    W = bf(torch.randn(N, K, device=DEV) * 0.05)
+    b = torch.randn(N, device=DEV) * 0.1
+    kw = dict(bias=b)
+    if case.startswith('gate_res'):
+        kw.update(epi=ops.EPI_GATE_RES, res=torch.randn(M, N, device=DEV), gate=torch.randn(M // L, N, device=DEV), gate_ld=N,
+                  rows_per_sample=L, no_out=(case == 'gate_res'))
+    elif case == 'dgelu_colsum':
+        kw.update(epi=ops.EPI_DGELU, bias=None, aux=bf(torch.randn(M, N, device=DEV)))
+    elif case == 'gelu':
+        kw.update(epi=ops.EPI_GELU)
+    else:
+        kw.update(epi=ops.EPI_BF16)
+    want_cs = case in ('dgelu_colsum', 'plain_colsum')
+    lib = _lib.lib()
+    got = {}
+    try:
+        for v, cus in ((1, 0), (2, 32), (2, 0)):
+            lib.mdt_set_tuning(b'gemm_nt_variant', v)
+            lib.mdt_set_tuning(b'nt8_max_cus', cus)
+            cs = torch.zeros(N, device=DEV) if want_cs else None
+            got[v, cus] = tuple(ops.gemm_nt(A, W, colsum=cs, **kw)) + (cs,)
+    finally:
+        lib.mdt_set_tuning(b'gemm_nt_variant', 0)
+        lib.mdt_set_tuning(b'nt8_max_cus', 0)
+    for key in ((2, 32), (2, 0)):
+        for idx, (x, y) in enumerate(zip(got[1, 0], got[key])):
+            assert (x is None) == (y is None)
+            if x is None:
+                continue
+            if idx == 3:
+                close(y, x, 3e-4, f'{case} {key} column sums')
+            elif case == 'dgelu_colsum':  # last-bit FMA contraction differences: at most one bf16 ulp on a small fraction
+                xf, yf = x.float(), y.float()
+                bad = xf != yf
+                assert bad.float().mean().item() < 2e-2
+                assert bool(((xf - yf).abs() <= 2.0 ** -7 * xf.abs().clamp_min(1e-30))[bad].all())
+            else:
+                assert torch.equal(x, y), f'{case} {key}: output {idx} differs from the 128x128 kernel'
+    # and against fp32 arithmetic on a row sample (the 128x128 kernel is itself checked in test_gemm_nt_epilogues)
+    rows = torch.arange(0, M, 257, device=DEV)
+    ref = A[rows].float() @ W.float().t() + (0 if kw['bias'] is None else b)
+    out = got[2, 32][0]
+    if case in ('plain', 'plain_colsum'):
+        close(out[rows], ref, 1e-2, f'{case} vs fp32')
 
 
 def test_activation_functions_vs_torch():

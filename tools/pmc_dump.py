@@ -7,4 +7,4 @@ for path in glob.glob(sys.argv[1] + '/**/*.db', recursive=True):
         by.setdefault(k, {})[c] = (n, v)
     for k, d in by.items():
         if 'tn8' not in k and 'nt8' not in k: continue
-        print(k[:60], {c: f'{v:.3g}' for c, (n, v) in d.items()}, 'launches', next(iter(d.values()))[0])
+        print(k[:70], {c: f'{v:.3g}' for c, (n, v) in d.items()}, 'launches', next(iter(d.values()))[0])
