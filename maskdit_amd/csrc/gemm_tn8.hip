@@ -72,7 +72,11 @@ template <int N> __device__ __forceinline__ void tn8_wait() {
 
 // SWAP = false: out tile rows = x (C[x, y]);  SWAP = true: the MFMA operands trade places so that the
 // accumulator tile is [y rows][x cols] and the atomics to C[y, x] stay lane-contiguous.
-template <bool SWAP, int YF>
+// FINE (round 3): no half-phase stagger; instead ONE memory operation (a fragment = two transpose reads, or one LDS-DMA
+// piece) pinned behind each of the phase's first MFMAs -- the form that gave gemm_nt8's K loop +13 %.
+// CS: the fused column sums of X (a template flag since round 3: their 13 registers and the branch in the middle of
+// every phase are only paid by the one launch per block that uses them, the qkv weight gradient).
+template <bool SWAP, int YF, bool FINE, bool CS>
 __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TN8Params p) {
   using Cfg = TN8Cfg<YF>;
   constexpr int NSLOT = Cfg::NSLOT, SLOT_BYTES = Cfg::SLOT_BYTES;
@@ -112,13 +116,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TN8Params p) {
   const long x_step = 64L * p.ldx, y_step = 64L * p.ldy;  // bytes per slot
   char* const lds_w = smem + wave * 1024;
 
-  auto issue = [&](int slot, int s) {  // fill ring slot `slot` with contraction rows of phase s
+  auto issue = [&](int slot, int s, int parts = 15) {  // fill ring slot `slot` with contraction rows of phase s
     if (p.dbg & 4) s &= 7;  // timing experiment: re-read the first 8 slots (cache-resident source)
     char* base = lds_w + slot * SLOT_BYTES;
-    glds16(xu + s * x_step + opaque(x_lo0), base);
-    glds16(xu + s * x_step + opaque(x_lo1), base + 8192);
-    glds16(yu + s * y_step + opaque(y_lo), base + 16384);
-    if (YF == 6 && mover2) glds16(yu + s * y_step + opaque(y_lo2), base + 24576);
+    if (parts & 1) glds16(xu + s * x_step + opaque(x_lo0), base);
+    if (parts & 2) glds16(xu + s * x_step + opaque(x_lo1), base + 8192);
+    if (parts & 4) glds16(yu + s * y_step + opaque(y_lo), base + 16384);
+    if ((parts & 8) && YF == 6 && mover2) glds16(yu + s * y_step + opaque(y_lo2), base + 24576);
   };
   // wait until all but this wave's loads of the newest `SLOTS` ring slots have landed
 #define TN8_WAIT_SLOTS(SLOTS)                                     \
@@ -138,12 +142,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TN8Params p) {
   // instruction delays the DMAs queued behind it far more than the earlier L2 fill saves.  Where the time goes (knob
   // tn8_dbg): MFMAs + barriers alone 828 us, + transpose reads 871, + refills from cache-resident rows 1020, + refills
   // of the real stream (HBM latency) 1165.
-  const bool late = wave >= 4;
+  const bool late = !FINE && wave >= 4;
   // ---- optional column sums of X (the bias gradient of the layer whose weight gradient this is): the 32 x 256 X slot
   // of every phase is in LDS anyway.  The tiles_y workgroups that share an X tile split its 32 16-byte column chunks
   // between them; thread (row = tid >> 4, c = tid & 15) reads chunk c_begin + c of slot row `row` -- one ds_read_b128 per
   // phase in the same half (and under the same lgkmcnt(0)) as the transpose reads of that slot, consumed in the MFMA half.
-  const bool do_cs = p.colsum_x != nullptr;
+  constexpr bool do_cs = CS;
   const int cs_begin = ty * 32 / p.tiles_y, cs_n = (ty + 1) * 32 / p.tiles_y - cs_begin;
   const int cs_row = tid >> 4, cs_c = tid & 15;
   const bool cs_on = do_cs && cs_c < cs_n;
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TN8Params p) {
   tn8_wait<63>();  // lgkmcnt(0): every wave's reads of slot 0 retired before it is refilled
   TN8_BARRIER()
   TN8_CS_ADD()
-  if (late) TN8_BARRIER()
+  if (!FINE && late) TN8_BARRIER()
 
   // one phase; K is a literal so that ring slot, register set and instruction offsets are static
 #define TN8_PHASE(K)                                                                                    \
@@ -266,12 +270,61 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TN8Params p) {
       }                                                                                                 \
     }                                                                                                   \
   }
-  for (int g0 = 0; g0 < S; g0 += Cfg::UNROLL) {
-    TN8_PHASE(0) TN8_PHASE(1) TN8_PHASE(2) TN8_PHASE(3) TN8_PHASE(4) TN8_PHASE(5)
-    TN8_PHASE(6) TN8_PHASE(7) TN8_PHASE(8) TN8_PHASE(9)
+  // FINE phase: MFMA q is followed by memory operation q: fragments X0..X3, Y0..Y(YF-1) of slot K+1 (two transpose
+  // reads each) behind MFMAs 0 .. 3+YF, the 4 (YF = 6) / 3 LDS-DMA pieces of the refill of slot K behind MFMAs
+  // YF+5, +DSTR, ...
+  constexpr int DSTR = YF == 6 ? 3 : 2, NPART = YF == 6 ? 4 : 3;
+#define TN8_FRAG(set, slot, f)                                                                          \
+  {                                                                                                     \
+    constexpr int so = ((slot) % 3) * SLOT_BYTES;                                                       \
+    if ((f) < 4) Xr[set][(f)] = cat4(tn8_tr_read<so>(xa[(slot) / 3][(f)]), tn8_tr_read<so + 1024>(xa[(slot) / 3][(f)])); \
+    else if ((f) < 8) Yr[set][(f) - 4] = cat4(tn8_tr_read<so>(ya[(slot) / 3][(f) - 4]), tn8_tr_read<so + 1024>(ya[(slot) / 3][(f) - 4])); \
+    else Yr[set][(f) - 4] = cat4(tn8_tr_read<so>(ya[(slot) / 3][(f) - 4]), tn8_tr_read<so + 512>(ya[(slot) / 3][(f) - 4])); \
   }
-  if (!late) TN8_BARRIER()
+  // STEADY: every condition is known (the main loop runs while whole unrolled groups have reads AND refills): no
+  // branch inside the phase -- a run-time `if` around a read puts an s_cbranch behind every MFMA
+#define TN8_PHASE_FINE(K, STEADY)                                                                       \
+  if constexpr ((K) < Cfg::UNROLL) {                                                                    \
+    const int ph = g0 + (K);                                                                            \
+    if (STEADY || ph < S) {                                                                             \
+      const bool do_reads = STEADY || (ph + 1 < S && !(p.dbg & 2)), do_dma = STEADY || (ph + NSLOT < S && !(p.dbg & 1)); \
+      _Pragma("unroll") for (int q = 0; q < 4 * YF; ++q) {                                              \
+        TN8_MFMA((K) & 1, q / YF, q % YF)                                                               \
+        if (q < 4 + YF) { if (do_reads) TN8_FRAG(((K) + 1) & 1, ((K) + 1) % NSLOT, q) }                 \
+        else if (q == 4 + YF) { if (do_reads) TN8_CS_READ(((K) + 1) % NSLOT) }                          \
+        else if (q >= YF + 5 && (q - YF - 5) % DSTR == 0 && (q - YF - 5) / DSTR < NPART) {              \
+          if (do_dma) issue((K) % NSLOT, ph + NSLOT, 1 << ((q - YF - 5) / DSTR));                       \
+        }                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+      }                                                                                                 \
+      if (STEADY || ph + NSLOT + 1 <= S) TN8_WAIT_PHASE()                                               \
+      else tn8_wait<0>();                                                                               \
+      TN8_BARRIER()                                                                                     \
+      if (do_reads) TN8_CS_ADD()                                                                        \
+    }                                                                                                   \
+  }
+  if constexpr (FINE) {
+    int g0 = 0;
+    if (!(p.dbg & 3)) {
+      for (; g0 + Cfg::UNROLL + NSLOT <= S; g0 += Cfg::UNROLL) {
+        TN8_PHASE_FINE(0, true) TN8_PHASE_FINE(1, true) TN8_PHASE_FINE(2, true) TN8_PHASE_FINE(3, true) TN8_PHASE_FINE(4, true)
+        TN8_PHASE_FINE(5, true) TN8_PHASE_FINE(6, true) TN8_PHASE_FINE(7, true) TN8_PHASE_FINE(8, true) TN8_PHASE_FINE(9, true)
+      }
+    }
+    for (; g0 < S; g0 += Cfg::UNROLL) {
+      TN8_PHASE_FINE(0, false) TN8_PHASE_FINE(1, false) TN8_PHASE_FINE(2, false) TN8_PHASE_FINE(3, false) TN8_PHASE_FINE(4, false)
+      TN8_PHASE_FINE(5, false) TN8_PHASE_FINE(6, false) TN8_PHASE_FINE(7, false) TN8_PHASE_FINE(8, false) TN8_PHASE_FINE(9, false)
+    }
+  } else {
+    for (int g0 = 0; g0 < S; g0 += Cfg::UNROLL) {
+      TN8_PHASE(0) TN8_PHASE(1) TN8_PHASE(2) TN8_PHASE(3) TN8_PHASE(4) TN8_PHASE(5)
+      TN8_PHASE(6) TN8_PHASE(7) TN8_PHASE(8) TN8_PHASE(9)
+    }
+    if (!late) TN8_BARRIER()
+  }
 #undef TN8_PHASE
+#undef TN8_PHASE_FINE
+#undef TN8_FRAG
 #undef TN8_LOAD
 #undef TN8_MFMA
 #undef TN8_WAIT_SLOTS
@@ -370,9 +423,14 @@ int launch_gemm_tn8(const bf16* A, int lda, const bf16* B, int ldb, int M, int N
     splits = (p.slots_total + p.slots_per_split - 1) / p.slots_per_split;
   }
   const dim3 grid(tiles * splits), block(512);
-#define TN8_LAUNCH(SW, YFV) hipLaunchKernelGGL((gemm_tn8_kernel<SW, YFV>), grid, block, 0, stream, p)
-  if (yf == 6) { if (p.swap) TN8_LAUNCH(true, 6); else TN8_LAUNCH(false, 6); }
-  else { if (p.swap) TN8_LAUNCH(true, 4); else TN8_LAUNCH(false, 4); }
+  const bool fine = (p.dbg & 8) == 0;  // tn8_dbg bit 3: the round-2 staggered form (A/B runs)
+  const bool cs = p.colsum_x != nullptr;  // (only with swap == 0: the column sums are those of the X operand = A)
+#define TN8_LAUNCH2(SW, YFV, CSV) { if (fine) hipLaunchKernelGGL((gemm_tn8_kernel<SW, YFV, true, CSV>), grid, block, 0, stream, p); \
+                                    else hipLaunchKernelGGL((gemm_tn8_kernel<SW, YFV, false, CSV>), grid, block, 0, stream, p); }
+#define TN8_LAUNCH(SW, YFV) { if (cs && !SW) TN8_LAUNCH2(SW, YFV, (!SW)) else TN8_LAUNCH2(SW, YFV, false) }
+  if (yf == 6) { if (p.swap) TN8_LAUNCH(true, 6) else TN8_LAUNCH(false, 6) }
+  else { if (p.swap) TN8_LAUNCH(true, 4) else TN8_LAUNCH(false, 4) }
+#undef TN8_LAUNCH2
 #undef TN8_LAUNCH
   return mdt_check_launch("gemm_tn8");
 }
