@@ -24,10 +24,36 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
-class GradSlabReducer:
-    """Averages ranges of a flat gradient tensor across the process group, asynchronously."""
+def _global_rank(pg, r: int) -> int:
+    """torch.distributed's src / dst arguments are GLOBAL ranks; `r` is a rank inside `pg`."""
+    return r if pg is None else dist.get_global_rank(pg, r)
 
-    def __init__(self, process_group=None, bucket_elems: int = 0):
+
+def slab_pieces(lo: int, hi: int, world: int):
+    """ZeRO-1 ownership of one gradient slab [lo, hi): W equal 8-element-aligned pieces (rank r owns piece r) plus a
+    tail shorter than 8 W elements that stays with the last rank.  Returns (q, [(a_0, e_0), ..., (a_{W-1}, e_{W-1})],
+    (tail_lo, tail_hi)); q = elements per equal piece (what reduce_scatter / all_gather move)."""
+    q = ((hi - lo) // world) // 8 * 8
+    pieces = [(lo + r * q, lo + (r + 1) * q) for r in range(world)]
+    return q, pieces, (lo + world * q, hi)
+
+
+class GradSlabReducer:
+    """Averages ranges of a flat gradient tensor across the process group, asynchronously.
+
+    Two exchange forms, both launched slab by slab from the backward plan:
+      * all-reduce (default): every rank ends with the mean of the slab;
+      * reduce-scatter (`set_zero_sharding()`, ZeRO-1): every slab is split W ways and rank r receives the mean of ITS
+        piece only -- ONE balanced `reduce_scatter_tensor` per slab (half the link bytes of an all-reduce, spread over
+        all links; round 2 sent whole slabs to single owners).  The parameter `all_gather_into_tensor` after the sharded
+        optimizer step is the other half (maskdit_amd/zero.py).
+    `wire_dtype=torch.bfloat16`: the slab is cast into a bf16 staging arena, exchanged in bf16 (half the bytes: 1.46
+    instead of 2.92 GB per step on XL/2) and accumulated back into the fp32 arena after the wait.
+    Backends: 'nccl' (= RCCL; AVG reduction, in-place reduce-scatter) and 'gloo' (CPU protocol tests, and two ranks on
+    one GPU: gloo moves CUDA tensors only through all_reduce / broadcast, so the reduce-scatter is an all-reduce whose
+    foreign pieces are simply not used)."""
+
+    def __init__(self, process_group=None, bucket_elems: int = 0, wire_dtype=None):
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
@@ -36,46 +62,60 @@ class GradSlabReducer:
         self.flat: Optional[torch.Tensor] = None
         self.enabled = True  # False inside no_sync() (gradient accumulation micro-steps)
         self.reduced_elems = 0
-        self.shard_bounds: Optional[List[int]] = None  # ZeRO-1: rank r owns arena elements [b[r], b[r+1])
+        self.wire_bytes = 0   # bytes handed to the collectives since the last reset (tests / logs)
+        self.zero = False
+        self.wire_dtype = wire_dtype if wire_dtype not in (None, torch.float32) else None
+        self.stage: Optional[torch.Tensor] = None
 
     def attach(self, flat_grad: torch.Tensor):
         self.flat = flat_grad
+        if self.wire_dtype is not None and self.world > 1:
+            self.stage = torch.empty(flat_grad.numel(), device=flat_grad.device, dtype=self.wire_dtype)
 
-    def set_owner_shards(self, bounds: List[int]):
-        """ZeRO-1 (maskdit_amd/zero.py): every gradient range is reduced TO THE RANK THAT OWNS ITS OPTIMIZER STATE
-        instead of all-reduced -- half the bytes on the links; the other half is the all-gather of the updated
-        parameters after the sharded optimizer step."""
-        assert len(bounds) == self.world + 1 and bounds[0] == 0 and all(a <= b for a, b in zip(bounds, bounds[1:]))
-        self.shard_bounds = list(bounds)
+    def set_zero_sharding(self, on: bool = True):
+        self.zero = bool(on)
 
-    def _reduce_piece(self, chunk: torch.Tensor, dst: Optional[int]):
+    # ---- one collective on one contiguous range -------------------------------------------------------------
+    def _launch(self, lo: int, hi: int, scatter_q: int = 0):
+        """all-reduce [lo, hi) (scatter_q = 0) or reduce-scatter it in W pieces of scatter_q elements."""
+        if hi <= lo:
+            return
         avg = self.backend == 'nccl'
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM  # gloo has no AVG: divide after the wait
-        if dst is None:
-            work = dist.all_reduce(chunk, op=op, group=self.pg, async_op=True)
-            self.pending.append((work, None if avg else chunk))
+        if self.stage is not None:
+            buf = self.stage[lo:hi]
+            buf.copy_(self.flat[lo:hi])  # fp32 -> wire dtype on the compute stream; the collective is ordered behind it
         else:
-            work = dist.reduce(chunk, dst=dst, op=op, group=self.pg, async_op=True)
-            self.pending.append((work, chunk if (not avg and dst == self.rank) else None))
+            buf = self.flat[lo:hi]
+        if scatter_q and avg:
+            mine = buf[self.rank * scatter_q:(self.rank + 1) * scatter_q]
+            work = dist.reduce_scatter_tensor(mine, buf, op=op, group=self.pg, async_op=True)
+            keep = (lo + self.rank * scatter_q, lo + (self.rank + 1) * scatter_q)
+        else:
+            work = dist.all_reduce(buf, op=op, group=self.pg, async_op=True)
+            keep = (lo, hi)
+        self.wire_bytes += buf.numel() * buf.element_size()
+        self.pending.append((work, keep, not avg))
 
     def reduce_range(self, name: str, lo: int, hi: int):
         if self.world == 1 or not self.enabled or hi <= lo:
             return
-        if self.shard_bounds is None:
-            self._reduce_piece(self.flat[lo:hi], None)
-        else:  # split the slab at the ownership boundaries: one reduce per owner
-            b = self.shard_bounds
-            for r in range(self.world):
-                a, e = max(lo, b[r]), min(hi, b[r + 1])
-                if a < e:
-                    self._reduce_piece(self.flat[a:e], r)
+        if not self.zero:
+            self._launch(lo, hi)
+        else:
+            q, _, tail = slab_pieces(lo, hi, self.world)
+            if q:
+                self._launch(lo, lo + self.world * q, scatter_q=q)
+            self._launch(tail[0], tail[1])  # < 8 W elements: plain all-reduce
         self.reduced_elems += hi - lo
 
     def finish(self):
-        for work, chunk in self.pending:
+        for work, (a, e), divide in self.pending:
             work.wait()
-            if chunk is not None:
-                chunk.div_(self.world)
+            if self.stage is not None:
+                self.flat[a:e].copy_(self.stage[a:e])  # back to fp32 (the optimizer reads the fp32 arena)
+            if divide:
+                self.flat[a:e].div_(self.world)
         self.pending.clear()
 
 
@@ -103,19 +143,20 @@ class DataParallel(nn.Module):
 
     `rccl_cus` (default: env MDT_RCCL_CUS or 16; only with the nccl backend and world > 1): CUs kept free of the
     persistent GEMM workgroups so that the slab all-reduces really run under the backward kernels
-    (reserve_cus_for_collectives)."""
+    (reserve_cus_for_collectives).  `grad_wire_dtype=torch.bfloat16`: gradient slabs travel as bf16 (config key
+    `train.grad_wire: bf16`)."""
 
-    def __init__(self, module: nn.Module, process_group=None, rccl_cus=None):
+    def __init__(self, module: nn.Module, process_group=None, rccl_cus=None, grad_wire_dtype=None):
         super().__init__()
         self.module = module
-        self.reducer = GradSlabReducer(process_group)
+        self.reducer = GradSlabReducer(process_group, wire_dtype=grad_wire_dtype)
         if self.reducer.world > 1 and self.reducer.backend == 'nccl':
             import os
             self.reserved_cus = int(os.environ.get('MDT_RCCL_CUS', '16')) if rccl_cus is None else int(rccl_cus)
             self.gemm_cus = reserve_cus_for_collectives(self.reserved_cus)
         eng = module.engine()
         if self.reducer.world > 1:
-            dist.broadcast(eng.P, src=0, group=process_group)
+            dist.broadcast(eng.P, src=_global_rank(process_group, 0), group=process_group)
             eng.shadows_dirty = True
         eng.ensure_grad()
         self.reducer.attach(eng.G)

@@ -239,6 +239,8 @@ JOBS = {
     # round 2: gradients on the BASELINE configs themselves (configs[1]: XL/2 256; configs[3]: T=1024 / L=512)
     'xl2_train': lambda: gen_train('xl2_train', 'DiT-XL/2', 32, 2, seed=5, with_grads=True),
     's2_512_train': lambda: gen_train('s2_512_train', 'DiT-S/2', 64, 2, seed=6, with_grads=True),
+    # round 3: configs[3] on the real model -- XL/2 at 512^2 latents (T = 1024, L = 512, hd 72), all gradients
+    'xl2_512_train': lambda: gen_train('xl2_512_train', 'DiT-XL/2', 64, 1, seed=8, with_grads=True),
     # configs[4]: XL/2, 50 Heun steps, cfg 1.5, the reference's fp32 network (sample.py:30-66)
     'xl2_sampler': lambda: gen_sampler('xl2_sampler', 'DiT-XL/2', 32, [0, 1], 50, 1.5, seed=7, nocfg=False),
 }

@@ -97,12 +97,77 @@ def _worker(rank, world, port, q):
         want = 3 * idx * 1e-6 * (sum(r + 1 for r in range(world)) / world) + 6.0
         assert torch.allclose(eng.G, want, rtol=1e-5, atol=1e-6)
         assert dp.reducer.reduced_elems == n
+        # --- ZeRO-1 exchange form: every slab reduce-scattered, rank r ends with the mean of ITS piece of every slab
+        from maskdit_amd.ddp import slab_pieces
+        from maskdit_amd.zero import owned_pieces
+        eng.G.zero_()
+        dp.reducer.set_zero_sharding(True)
+        dp.reducer.reduced_elems = 0
+        eng.fake_backward(rank, step=0.0)
+        dp.finish_grad_sync()
+        want = idx * 1e-6 * (sum(r + 1 for r in range(world)) / world)
+        mine = owned_pieces(eng.lay.slabs, world, rank)
+        assert sum(e - a for a, e in mine) >= n // world - 8 * world * len(eng.lay.slabs)
+        cover = torch.zeros(n, dtype=torch.int32)
+        for r in range(world):
+            for a, e in owned_pieces(eng.lay.slabs, world, r):
+                cover[a:e] += 1
+        assert bool((cover == 1).all()), 'the owned pieces of all ranks must tile the arena exactly once'
+        for a, e in mine:
+            assert torch.allclose(eng.G[a:e], want[a:e], rtol=1e-6, atol=1e-9)
+        assert dp.reducer.reduced_elems == n
+        dp.reducer.set_zero_sharding(False)
         q.put((rank, 'ok'))
     except Exception as e:  # noqa: BLE001
         import traceback
         q.put((rank, 'FAIL: ' + traceback.format_exc()))
     finally:
         dist.destroy_process_group()
+
+
+def _wire_worker(rank, world, port, q):
+    """bf16 gradient transport: slabs are cast into a bf16 staging arena, exchanged, accumulated back in fp32."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from maskdit_amd.engine import make_spec
+        from maskdit_amd.ddp import DataParallel
+        eng = FakeEngine(make_spec('DiT-S/2', 32, 4, 1000))
+        dp = DataParallel(FakeModule(eng), grad_wire_dtype=torch.bfloat16)
+        n = eng.lay.n
+        g = torch.Generator().manual_seed(100 + rank)
+        local = torch.randn(n, generator=g)
+        both = [torch.randn(n, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+        for name, lo, hi in eng.backward_order():
+            eng.G[lo:hi] = local[lo:hi]
+            eng.grad_slab_hook(name, lo, hi)
+        dp.finish_grad_sync()
+        assert dp.reducer.wire_bytes == 2 * n, 'bf16 wire: 2 bytes per gradient element'
+        want = sum(b.bfloat16().float() for b in both) / world
+        err = ((eng.G - want).abs().max() / want.abs().max()).item()
+        assert err <= 1e-2, f'bf16-wire mean differs: {err:.3e}'  # one bf16 rounding of the sum
+        assert eng.G.dtype == torch.float32
+        q.put((rank, 'ok'))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, 'FAIL: ' + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_bf16_gradient_wire_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_wire_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in procs]
+    for p in procs:
+        p.join(30)
+    assert all(r[1] == 'ok' for r in res), res
 
 
 @pytest.mark.timeout(180)

@@ -117,8 +117,8 @@ def test_two_rank_data_parallel(backend):
 
 
 def _zero_worker(rank, world, port, q):
-    """ZeRO-1 (maskdit_amd/zero.py): reduce-to-owner gradients + sharded AdamW/EMA + parameter all-gather must give
-    the unsharded result."""
+    """ZeRO-1 (maskdit_amd/zero.py): reduce-scattered gradient slabs (rank r owns piece r of every slab) + sharded
+    AdamW/EMA + parameter all-gather must give the unsharded result."""
     sys.path.insert(0, ROOT)
     import copy
     import torch.distributed as dist
@@ -160,14 +160,14 @@ def _zero_worker(rank, world, port, q):
         ema = copy.deepcopy(net).eval()
         dp = M.DataParallel(net)
         opt = M.ShardedFusedAdam(net.parameters(), data_parallel=dp, lr=1e-3)
-        assert opt._m.numel() <= net.engine().lay.n // world + 8, 'moments are not sharded'
+        assert opt._m.numel() <= net.engine().lay.n // world + 8 * world * len(net.engine().lay.slabs), 'moments are not sharded'
         opt.fuse_ema(ema, 0.99)
         ref = build()
         ref_ema = copy.deepcopy(ref).eval()
         ropt = M.FusedAdam(ref.parameters(), lr=1e-3)
         ropt.fuse_ema(ref_ema, 0.99)
         half = slice(rank * B // 2, (rank + 1) * B // 2)
-        bounds = opt._bounds
+        slabs = net.engine().lay.slabs
         for s in range(2):
             opt.zero_grad(set_to_none=True)
             run(dp, s, half).mean().backward()
@@ -175,11 +175,9 @@ def _zero_worker(rank, world, port, q):
             # the averaged gradient, assembled from the owners (each rank holds the reduced values of its own range only)
             G = net.engine().G
             Gfull = G.detach().clone()
-            for r in range(world):
-                if bounds[r] < bounds[r + 1]:
-                    dist.broadcast(Gfull[bounds[r]:bounds[r + 1]], src=r)
-            lo, hi = bounds[rank], bounds[rank + 1]
-            assert torch.equal(Gfull[lo:hi], G[lo:hi])
+            opt._gather(Gfull, slabs)  # every owner's reduced pieces (piece r of every slab belongs to rank r)
+            for lo, hi in opt._pieces:
+                assert torch.equal(Gfull[lo:hi], G[lo:hi])
             if s == 0:  # sanity of the reduce-to-owner gradient itself: the full-batch gradient within atomics noise
                 ref2 = build()
                 run(ref2, 0, slice(0, B)).mean().backward()
@@ -194,7 +192,13 @@ def _zero_worker(rank, world, port, q):
             M.update_ema(ema, net, 0.99)
             ropt.step()
             M.update_ema(ref_ema, ref, 0.99)
-        opt.sync_ema()
+        try:
+            opt.state_dict()
+            raise AssertionError('state_dict() on a sharded group without consolidate() must raise, not dead-lock')
+        except RuntimeError:
+            pass
+        opt.consolidate()  # collective: moments gathered, EMA arena current everywhere
+        sd = opt.state_dict() if rank == 0 else None  # the reference's rank-0-only save (train.py:259-264)
         sd = opt.state_dict()
         rsd = ropt.state_dict()
         worst = relg
@@ -212,6 +216,7 @@ def _zero_worker(rank, world, port, q):
             assert torch.equal(arena, other), 'replicas diverged'
         # a sharded checkpoint loads back into the sharded optimizer (and keeps the apex layout)
         opt.load_state_dict(sd)
+        opt.consolidate()
         sd2 = opt.state_dict()
         for i in sd['state']:
             assert torch.equal(sd['state'][i]['exp_avg_sq'], sd2['state'][i]['exp_avg_sq'])

@@ -164,3 +164,38 @@ def test_generate_with_vae_decode_writes_images(tmp_path):
     import PIL.Image
     im = np.asarray(PIL.Image.open(os.path.join(tmp, 'img', files[1])))
     assert im.shape == (256, 256, 3) and im.dtype == np.uint8 and im.std() > 1.0
+
+
+def test_bench_two_ranks_on_one_device():
+    """bench.py's N > 1 path end to end (its `world > 1` branches had never executed): launched exactly as
+    the driver does (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 ...`), with the test hook
+    MDT_BENCH_ONE_DEVICE=1 putting both ranks on cuda:0 over gloo (RCCL needs one device per rank; the driver's 8-GPU run
+    uses `nccl`).  XL/2 at global batch 256 so that two replicas fit one GPU.  Checks the ONE JSON line of rank 0: N, the
+    strong-scaling split of the global batch, a finite loss and the whole-job throughput arithmetic."""
+    import gc
+    import json
+    import socket
+    import subprocess
+    gc.collect()               # nets / plans of earlier tests in this process (up to ~240 GB of saved activations)
+    torch.cuda.empty_cache()   # must be back with the driver before two more replicas start on the same device
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MDT_BENCH_ONE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1',
+           '--no-cpu-baseline', '--no-sampler', '--global-batch', '256']
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, f'expected ONE JSON line from rank 0, got {len(lines)}'
+    rec = json.loads(lines[0])
+    assert rec['n_gpus'] == 2 and rec['steps'] == 1 and rec['warmup'] == 1 and rec['scaling'] == 'strong'
+    cfg = rec['config']
+    assert cfg['global_batch'] == 256 and cfg['per_gpu_batch'] == 128 and cfg['parallelism'] == 'dp2'
+    assert np.isfinite(rec['mean_loss']) and 0 < rec['mean_loss'] < 100
+    assert abs(rec['value'] - 256 / (rec['ms_per_step'] * 1e-3)) <= 0.02 * rec['value']
+    assert rec['roofline'] is not None and rec['roofline']['launches'] > 0

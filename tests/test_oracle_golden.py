@@ -85,7 +85,8 @@ def test_forward_loss_matches_reference(golden_dir, name, model, R):
 
 @pytest.mark.parametrize('name,model,R', [('s2_train.npz', 'DiT-S/2', 32),        # BASELINE configs[0]
                                           ('xl2_train.npz', 'DiT-XL/2', 32),     # configs[1]: the benched model
-                                          ('s2_512_train.npz', 'DiT-S/2', 64)])  # configs[3] shapes: T = 1024, L = 512
+                                          ('s2_512_train.npz', 'DiT-S/2', 64),   # configs[3] shapes: T = 1024, L = 512
+                                          ('xl2_512_train.npz', 'DiT-XL/2', 64)])  # configs[3]: XL/2 at 512^2 latents
 def test_train_step_matches_reference(golden_dir, name, model, R):
     """loss, EVERY parameter gradient (L2 norm + 64 sampled entries per tensor), one AdamW + EMA step --
     against what the reference itself produced (tests/golden/make_golden.py: gen_train)."""
