@@ -65,6 +65,9 @@ def parse():
     ap.add_argument('--no-sampler', action='store_true', help='skip the EDM sampler leg (BASELINE configs[4])')
     ap.add_argument('--sampler-batch', type=int, default=64)
     ap.add_argument('--sampler-steps', type=int, default=50)
+    ap.add_argument('--zero1', action='store_true', help='N > 1: ZeRO-1 (maskdit_amd.ShardedFusedAdam: reduce-scattered gradient '
+                                                          'slabs, sharded AdamW + EMA, parameter all-gather)')
+    ap.add_argument('--grad-wire', default='fp32', choices=['fp32', 'bf16'], help='N > 1: dtype of the gradient slabs on the links')
     return ap.parse_args()
 
 
@@ -315,9 +318,12 @@ def main():
     ema = copy.deepcopy(net).eval()
     for p in ema.parameters():
         p.requires_grad_(False)
-    opt = M.FusedAdam(net.parameters(), lr=1e-4, adam_w_mode=True, weight_decay=0)
+    model = M.DataParallel(net, grad_wire_dtype=torch.bfloat16 if args.grad_wire == 'bf16' else None) if world > 1 else net
+    if args.zero1 and world > 1:
+        opt = M.ShardedFusedAdam(net.parameters(), data_parallel=model, lr=1e-4, adam_w_mode=True, weight_decay=0)
+    else:
+        opt = M.FusedAdam(net.parameters(), lr=1e-4, adam_w_mode=True, weight_decay=0)
     opt.fuse_ema(ema, 0.9999)
-    model = M.DataParallel(net) if world > 1 else net
     loss_fn = M.Losses['edm']()
     if args.micro_batch <= 0:
         # saved activations of one training pass: bf16/fp32 tensors listed in DESIGN.md section 2
@@ -404,9 +410,14 @@ def main():
                 try:
                     rec = json.load(open(pmc))
                     # only a PMC pass of THIS workload counts (profiles/pmc_gemm_nt.json states its command)
+                    # ... and only one taken on THIS build of the kernels (source hash of maskdit_amd/csrc + include)
                     if (rec.get('model'), rec.get('resolution'), rec.get('micro_batch')) == (args.model, R, mb):
-                        roof['traffic'] = rec.get('hbm_bytes_per_launch')
-                        roof['traffic_source'] = rec.get('command')
+                        if rec.get('source_hash') == _lib.source_hash():
+                            roof['traffic'] = rec.get('hbm_bytes_per_launch')
+                            roof['traffic_source'] = rec.get('command')
+                        else:
+                            roof['traffic_source'] = (f"profiles/pmc_gemm_nt.json was taken on another build (source hash "
+                                                      f"{rec.get('source_hash')} != {_lib.source_hash()}): not reported")
                 except Exception:
                     pass
             sp_ms = timer.span_ms()
@@ -487,7 +498,8 @@ def main():
             'config': {'workload': f'{args.model} ImageNet{R * 8}-latent [{R}x{R}x4], mask_ratio=0.5, mae_loss_coef=0.1, '
                                    f'sample(moments)+class-dropout+fwd+bwd+grad-allreduce+AdamW+EMA, random-init (de-zeroed) weights',
                        'global_batch': args.global_batch, 'per_gpu_batch': per_gpu, 'micro_batch': mb, 'accum': accum,
-                       'tokens_per_sample': (R // 2) ** 2, 'kept_tokens': (R // 2) ** 2 // 2, 'parallelism': f'dp{world}'},
+                       'tokens_per_sample': (R // 2) ** 2, 'kept_tokens': (R // 2) ** 2 // 2,
+                       'parallelism': f'dp{world}' + ('+zero1' if args.zero1 and world > 1 else '') + ('+bf16grads' if args.grad_wire == 'bf16' and world > 1 else '')},
             'model_tflops_per_s': round(value * 392.7e9 / 1e12, 1) if (args.model, R) == ('DiT-XL/2', 32) else None,
             'mean_loss': round(mean_loss, 5),
             'roofline': roof, 'sampler': sampler, 'cpu_baseline': cpu,

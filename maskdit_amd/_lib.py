@@ -96,6 +96,21 @@ class MaskDiTLibError(RuntimeError):
     pass
 
 
+def source_hash() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources the library is built from: identifies the BINARY a profile
+    was taken on (bench.py refuses a PMC traffic record of another build)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(os.path.abspath(__file__))
+    files = sorted(glob.glob(os.path.join(root, 'csrc', '*.hip')) + glob.glob(os.path.join(root, 'csrc', '*.h')) +
+                   glob.glob(os.path.join(root, '..', 'include', '*.h')))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def build(verbose: bool = False) -> str:
     """Compile csrc/*.hip for gfx950 into libmaskdit_hip.so (hipcc cross-compiles without a GPU)."""
     r = subprocess.run(['make', '-C', CSRC, '-j', str(min(8, os.cpu_count() or 1))], capture_output=True, text=True)

@@ -1400,16 +1400,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv_res_kernel(const bf16* __r
     default: mdt_set_error("attention: head_dim must be one of 32, 64, 72, 80"); return MDT_ERR_ARG; \
   }
 
-static int attn_num_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-    if (n <= 0) n = 256;
-  }
-  return n;
-}
+// the persistent attention grids honour the same CU cap as the persistent GEMMs ("nt8_max_cus": CUs left to a
+// concurrent RCCL kernel under data parallelism, maskdit_amd/ddp.py) -- a multiple of 8 keeps the XCD affinity
+int nt8_num_cus();
+static int attn_num_cus() { return nt8_num_cus() & ~7; }
 
 extern "C" int mdt_attn_fwd(const mdt_bf16* qkv, mdt_bf16* out, float* lse, int B, int L, int H, int hd, int L_valid,
                             mdt_stream_t stream) {

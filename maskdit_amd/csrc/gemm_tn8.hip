@@ -404,14 +404,17 @@ int launch_gemm_tn8(const bf16* A, int lda, const bf16* B, int ldb, int M, int N
   const int nslot = yf == 6 ? TN8Cfg<6>::NSLOT : TN8Cfg<4>::NSLOT;
   p.slots_total = M / 32;
   const int tiles = p.tiles_x * p.tiles_y;
-  // split the contraction: minimise (waves of 256 workgroups) x (slots per split + fixed per-block cost
+  const int cus = nt8_num_cus();  // the CU count the data-parallel wrapper leaves to compute ("nt8_max_cus"): the grid is not
+                                  // persistent, so a concurrent RCCL kernel gets CUs as workgroups retire; the split only
+                                  // has to be sized for the CUs that are really available
+  // split the contraction: minimise (waves of `cus` workgroups) x (slots per split + fixed per-block cost
   // ~ prologue latency + 32K-48K epilogue atomics, worth about 48 slots of MFMA work)
   int best = 1;
   double best_cost = 1e30;
   for (int sp = 1; sp <= 64; ++sp) {
     if (sp > 1 && p.slots_total / sp < 32) break;
     const long blocks = (long)tiles * sp;
-    const double cost = (double)((blocks + 255) / 256) * ((double)((p.slots_total + sp - 1) / sp) + 48.0);
+    const double cost = (double)((blocks + cus - 1) / cus) * ((double)((p.slots_total + sp - 1) / sp) + 48.0);
     if (cost < best_cost * 0.98) { best_cost = cost; best = sp; }
   }
   p.slots_per_split = (p.slots_total + best - 1) / best;

@@ -274,7 +274,8 @@ class Engine:
         self._t_table = torch.tensor(tab, dtype=torch.int64, device=dev)
         self._t_tiles = tiles
         self.shadows_dirty = True
-        self._plans: Dict[tuple, 'PassPlan'] = {}
+        self._plans: Dict[tuple, 'PassPlan'] = {}   # insertion order = LRU order (plan() re-inserts on every hit)
+        self.plan_budget = 0.80                     # fraction of the device memory all cached plans may hold
         self.grad_slab_hook: Optional[Callable[[str, int, int], None]] = None  # DP overlap (ddp.py)
         self.ema_applied = None
         LIVE_ENGINES.add(self)
@@ -311,17 +312,31 @@ class Engine:
         (PassPlan.set_valid)."""
         Lv = (L if L is not None else self.sp.T // 2) if masked else None
         key = (B, masked, train, _rup(Lv, 64) if masked else None)
-        pl = self._plans.get(key)
+        pl = self._plans.pop(key, None)
         if pl is None:
-            if train:  # one training plan holds ~0.2 GB of activations per sample: never two shapes at once
-                for k in [k for k in self._plans if k[2]]:
-                    self._plans.pop(k)
-            if len(self._plans) >= 4:  # buffers are large: keep few shapes alive
+            # LRU cache under a memory budget (ADVICE r2: round 2 dropped EVERY training plan whenever another training
+            # shape was requested, so alternating masked / unmasked forwards or a ragged last micro-batch rebuilt ~0.2 GB
+            # per sample of buffers -- and any instrumentation patched onto a plan -- on every call).  A new plan evicts
+            # least-recently-used ones only while the plans' bytes exceed `plan_budget` of the device memory, or while
+            # its own allocation fails; at most 8 shapes are kept.
+            while len(self._plans) >= 8:
                 self._plans.pop(next(iter(self._plans)))
-            pl = PassPlan(self, B, masked, train, Lv)
-            self._plans[key] = pl
+            need = PassPlan.estimate_bytes(self.sp, B, masked, train, Lv)
+            budget = self.plan_budget * torch.cuda.get_device_properties(self.device).total_memory
+            while self._plans and sum(p.nbytes for p in self._plans.values()) + need > budget:
+                self._plans.pop(next(iter(self._plans)))
+            while True:
+                try:
+                    pl = PassPlan(self, B, masked, train, Lv)
+                    break
+                except torch.cuda.OutOfMemoryError:
+                    if not self._plans:
+                        raise
+                    self._plans.pop(next(iter(self._plans)))
+                    torch.cuda.empty_cache()
         elif masked:
             pl.set_valid(Lv)
+        self._plans[key] = pl  # most recently used = last
         return pl
 
     def release_plans(self):
@@ -376,6 +391,20 @@ class PassPlan:
         self.bwd = Plan()
         self.gen = 0  # forward generation: the saved activations belong to the LAST forward through this plan
         self._build()
+
+    @property
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.buf.values())
+
+    @staticmethod
+    def estimate_bytes(sp, B: int, masked: bool, train: bool, Lv: Optional[int]) -> int:
+        """Upper estimate of a plan's buffers before it is built (measured: 244 GB in use for XL/2 at B = 1024 incl.
+        30 GB of arenas; inference plans keep one block's worth of activations)."""
+        L = _rup(Lv, 64) if masked else sp.T
+        per_tok_enc = 40 * sp.D if train else 0      # bytes of saved activations per encoder token and block
+        per_tok_dec = 40 * sp.Dd if train else 0
+        live = 64 * max(sp.D, sp.Dd) * sp.T          # per-sample working set of one block (fwd-only plans)
+        return int(B * (sp.depth * per_tok_enc * L + sp.ddepth * per_tok_dec * sp.T + live) * 1.05)
 
     def set_valid(self, Lv: int):
         if _rup(Lv, 64) != self.L or not (1 <= Lv <= self.T):

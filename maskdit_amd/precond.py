@@ -213,6 +213,7 @@ class EDMPrecond(nn.Module):
         self.model = DiT(self.spec)
         self._engine: Optional[Engine] = None
         self._seen_version = -1
+        self._plist = None
 
     # ---- engine binding ------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
@@ -245,6 +246,7 @@ class EDMPrecond(nn.Module):
                 p.grad = None
         self._engine = eng
         self._seen_version = -1
+        self._plist = None
 
     def engine(self) -> Engine:
         if self._engine is None:
@@ -258,7 +260,10 @@ class EDMPrecond(nn.Module):
         # optimizer) bumps THAT parameter's version counter (after `p.data = view` a Parameter keeps its own
         # counter, the arena's does not move) -> the bf16 / K-major shadows are stale.  The engine's own
         # optimizer kernel writes the arena and the shadows together and bumps nothing.
-        v = eng.P._version + eng.pos._version + eng.dpos._version + sum(p._version for p in self.parameters())
+        plist = self._plist
+        if plist is None:  # (the module tree is fixed after construction: walk it once, not on every forward)
+            plist = self._plist = tuple(self.parameters())
+        v = eng.P._version + eng.pos._version + eng.dpos._version + sum([p._version for p in plist])
         if v != self._seen_version:
             eng.shadows_dirty = True
             self._seen_version = v

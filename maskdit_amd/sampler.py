@@ -8,7 +8,9 @@ bump -- is captured ONCE into a hipGraph on a side stream; every step replays th
 reading its scalars (t_i, t_{i+1}) from a device-side fp64 schedule indexed by a device-side
 counter.  The last step (no 2nd-order correction, sample.py:61) replays a second, shorter graph.
 `use_graph=False` issues the SAME launch sequence directly on the stream (no capture): same kernels, same bits.
-Stochastic churn (S_churn > 0; sample.py:51-53) is outside every shipped configuration and raises.
+Stochastic churn (S_churn > 0; sample.py:51-53; no shipped configuration) runs every network evaluation on the HIP
+forward plan with the step's fp64 state algebra in torch (`_churn_steps`), checked against the reference fixture
+`s2_sampler_churn.npz`.
 """
 from __future__ import annotations
 
@@ -122,6 +124,27 @@ def _graphed(net: EDMPrecond, B: int, use_cfg: bool) -> _GraphedHeun:
     return g
 
 
+def _churn_steps(net, x, t_steps, class_labels, cfg_scale, randn_like, num_steps, S_churn, S_min, S_max, S_noise):
+    """The S_churn > 0 branch of sample.py:46-64.  Not graph-captured: gamma depends on the host-side schedule."""
+    gamma_max = min(S_churn / num_steps, 2.0 ** 0.5 - 1.0)
+    ts = [float(v) for v in t_steps.tolist()]
+
+    def denoise(state, sigma):
+        sig = torch.tensor(sigma, dtype=torch.float64, device=state.device)
+        return net(state.float(), sig, class_labels, cfg_scale)['x'].to(torch.float64)
+
+    for i in range(num_steps):
+        t_cur, t_next = ts[i], ts[i + 1]
+        t_hat = t_cur * (1.0 + (gamma_max if S_min <= t_cur <= S_max else 0.0))   # round_sigma = identity (maskdit.py:775)
+        x_hat = x + ((t_hat * t_hat - t_cur * t_cur) ** 0.5 * S_noise) * randn_like(x)
+        slope = (x_hat - denoise(x_hat, t_hat)) / t_hat
+        x = x_hat + (t_next - t_hat) * slope                                       # Euler
+        if i + 1 < num_steps:                                                      # Heun average (not on the last step)
+            slope2 = (x - denoise(x, t_next)) / t_next
+            x = x_hat + (t_next - t_hat) * 0.5 * (slope + slope2)
+    return x
+
+
 @torch.no_grad()
 def edm_sampler(net, latents, class_labels=None, cfg_scale=None, feat=None, randn_like=torch.randn_like, num_steps=18,
                 sigma_min=0.002, sigma_max=80, rho=7, S_churn=0, S_min=0, S_max=float('inf'), S_noise=1, use_graph=True):
@@ -142,8 +165,9 @@ def edm_sampler(net, latents, class_labels=None, cfg_scale=None, feat=None, rand
     labels = raw._labels(class_labels, B, latents.device)
     x_next = latents.to(torch.float64) * t_steps[0]  # sample.py:46
     if S_churn != 0:
-        raise NotImplementedError('edm_sampler: S_churn > 0 (stochastic sampling) is outside the shipped configurations '
-                                  '(configs/test/*.yaml, generate.py defaults: S_churn = 0)')
+        # stochastic churn (sample.py:51-53; no shipped config uses it): every network evaluation is the HIP forward
+        # plan, the fp64 state algebra of the step -- which now carries a per-step noise level t_hat != t_i -- is torch
+        return _churn_steps(raw, x_next, t_steps, class_labels, cfg_scale, randn_like, num_steps, S_churn, S_min, S_max, S_noise)
 
     use_cfg = cfg_scale is not None
     g = _graphed(raw, B, use_cfg)

@@ -415,14 +415,18 @@ def edm_t_steps(num_steps, sigma_min=0.002, sigma_max=80.0, rho=7):
 
 
 def edm_sampler(P, cfg, latents, class_labels, cfg_scale=None, num_steps=18, sigma_min=0.002,
-                sigma_max=80.0, rho=7):
-    """sample.py:30-66 for S_churn = 0 (gamma = 0, x_hat = x_cur); fp64 state, fp32 net."""
+                sigma_max=80.0, rho=7, S_churn=0, S_min=0, S_max=float('inf'), S_noise=1, randn_like=torch.randn_like):
+    """sample.py:30-66; fp64 state, fp32 net.  S_churn = 0 (every shipped config): gamma = 0, x_hat = x_cur; the
+    stochastic branch (sample.py:51-53) draws one `randn_like` per step like the reference does."""
     t_steps = edm_t_steps(num_steps, sigma_min, sigma_max, rho)
     x_next = latents.to(torch.float64) * t_steps[0]
     with torch.no_grad():
         for i in range(num_steps):
             t_cur, t_next = t_steps[i], t_steps[i + 1]
-            x_hat, t_hat = x_next, t_cur
+            gamma = min(S_churn / num_steps, 2 ** 0.5 - 1) if S_min <= float(t_cur) <= S_max else 0
+            t_hat = t_cur + gamma * t_cur  # round_sigma is the identity for EDMPrecond (models/maskdit.py:775)
+            eps = randn_like(x_next)       # drawn even when its coefficient is 0 (generator state parity)
+            x_hat = x_next + (t_hat ** 2 - t_cur ** 2).sqrt() * S_noise * eps
             den = precond_forward(P, cfg, x_hat.float(), t_hat, class_labels, cfg_scale=cfg_scale,
                                   training=False).to(torch.float64)
             d_cur = (x_hat - den) / t_hat

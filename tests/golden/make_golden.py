@@ -173,6 +173,27 @@ def gen_sampler(tag, model_type, R, seeds, num_steps, cfg_scale, seed, nocfg=Tru
     print(f'{tag}.npz written; z std', z.std().item())
 
 
+def gen_sampler_churn(tag='s2_sampler_churn', seeds=(200, 201, 202), num_steps=6, seed=9):
+    """sample.py:51-53 with S_churn > 0: the stochastic branch (gamma > 0, x_hat = x_cur + noise) of the reference."""
+    cfg = O.make_cfg('DiT-S/2', img_resolution=32)
+    P = O.init_params(cfg, seed=seed, dezero=True)
+    net = build_ref('DiT-S/2', 32, P)
+    net.eval()
+    seeds = list(seeds)
+    rnd = StackedRandomGenerator('cpu', seeds)
+    latents = rnd.randn([len(seeds), 4, 32, 32])
+    cls = rnd.randint(1000, size=[len(seeds)])
+    labels = torch.eye(1000)[cls]
+    kw = dict(S_churn=10.0, S_min=0.05, S_max=50.0, S_noise=1.003)
+    with torch.no_grad():
+        z = ref_edm_sampler(net, latents.float(), labels.float(), randn_like=rnd.randn_like, cfg_scale=1.5,
+                            num_steps=num_steps, **kw)
+    np.savez_compressed(os.path.join(HERE, f'{tag}.npz'), seed=np.int64(seed), seeds=np.array(seeds), latents=latents.numpy(),
+                        cls=cls.numpy(), num_steps=np.int64(num_steps), cfg_scale=np.float64(1.5), z=z.numpy(),
+                        **{k: np.float64(v) for k, v in kw.items()})
+    print(f'{tag}.npz written; z std', z.std().item())
+
+
 def gen_moments():
     g = torch.Generator().manual_seed(5)
     mom = torch.cat([2.745 * torch.randn(4, 4, 32, 32, generator=g), torch.full((4, 4, 32, 32), -10.0)], 1)
@@ -240,6 +261,7 @@ JOBS = {
     'xl2_train': lambda: gen_train('xl2_train', 'DiT-XL/2', 32, 2, seed=5, with_grads=True),
     's2_512_train': lambda: gen_train('s2_512_train', 'DiT-S/2', 64, 2, seed=6, with_grads=True),
     # round 3: configs[3] on the real model -- XL/2 at 512^2 latents (T = 1024, L = 512, hd 72), all gradients
+    's2_sampler_churn': gen_sampler_churn,   # round 3: the S_churn > 0 branch (sample.py:51-53)
     'xl2_512_train': lambda: gen_train('xl2_512_train', 'DiT-XL/2', 64, 1, seed=8, with_grads=True),
     # configs[4]: XL/2, 50 Heun steps, cfg 1.5, the reference's fp32 network (sample.py:30-66)
     'xl2_sampler': lambda: gen_sampler('xl2_sampler', 'DiT-XL/2', 32, [0, 1], 50, 1.5, seed=7, nocfg=False),

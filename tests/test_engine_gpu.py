@@ -287,6 +287,27 @@ def test_sampler_vs_reference_fixture(golden_dir):
     assert e2 <= 4e-3
 
 
+def test_sampler_stochastic_churn_vs_reference_fixture(golden_dir):
+    """S_churn > 0 (sample.py:51-53; ADVICE r2: the branch used to raise): HIP network evaluations + torch fp64 state
+    algebra against the reference's own output with the same per-seed noise streams."""
+    g = _load(golden_dir, 's2_sampler_churn.npz')
+    cfg, P, net = _build('DiT-S/2', 32, int(g['seed']), train=False)
+    rnd = M.StackedRandomGenerator('cpu', [int(s) for s in g['seeds']])
+    lat = rnd.randn([len(g['seeds']), 4, 32, 32])
+    cls = rnd.randint(1000, size=[len(g['seeds'])])
+
+    def randn_like(x):  # the fixture's generators live on the CPU
+        return rnd.randn(list(x.shape), dtype=x.dtype).to(x.device)
+
+    z = M.edm_sampler(net, lat.to(DEV), torch.eye(1000)[cls].to(DEV), cfg_scale=float(g['cfg_scale']), num_steps=int(g['num_steps']),
+                      randn_like=randn_like, S_churn=float(g['S_churn']), S_min=float(g['S_min']), S_max=float(g['S_max']),
+                      S_noise=float(g['S_noise']))
+    assert z.dtype == torch.float64 and z.shape == lat.shape
+    e = _relmax(z, torch.from_numpy(g['z']))
+    print(f'sampler with churn: rel-to-max err {e:.3e}')
+    assert e <= 4e-3  # 11 bf16 network evaluations, as test_sampler_vs_reference_fixture
+
+
 def test_state_dict_roundtrip_and_rebinding():
     cfg, P, net = _build('DiT-S/2', 32, seed=6)
     sd = net.state_dict()
@@ -577,3 +598,47 @@ def test_arbitrary_mask_ratio_vs_oracle(golden_dir, ratio):
             worst = (k, num / (den + 1e-12))
         assert num <= TOL_GRAD * den + 1e-7, f'{k}: grad rel L2 err {num / (den + 1e-12):.3e}'
     print(f'ratio {ratio}: kept {Lv}, loss rel err {rl:.2e}, worst grad rel err {worst[1]:.2e} ({worst[0]})')
+
+
+def test_one_plan_serves_changing_kept_counts_and_plans_are_cached(golden_dir):
+    """(a) PassPlan.set_valid() -- ONE plan re-used with a different kept-token count inside the same 64-row
+    bucket (a mask-ratio schedule does this every step): 179 then 170 then 179 of 256 through the same net, each loss and
+    every gradient against the fp32 oracle at the exact count; (b) the plan cache is LRU under a memory budget: an
+    unmasked evaluation and a second training shape in between must NOT evict the training plan (round 2 dropped every
+    training plan whenever another training shape was requested, losing anything patched onto it)."""
+    g = _load(golden_dir, 's2_train.npz')
+    cfg, P, net = _build('DiT-S/2', 32, int(g['seed']))
+    images, labels, rnd, noise, mnoise = _inputs(g)
+    B, T = mnoise.shape
+    eng = net.engine()
+    plan_ids = []
+    for Lv in (179, 170, 179):
+        ratio = 1.0 - (Lv + 0.5) / T
+        assert int(T * (1 - ratio)) == Lv
+        md = M.get_mask(B, T, ratio, DEV, noise=mnoise.to(DEV))
+        net.zero_grad(set_to_none=True)
+        loss = M.Losses['edm']().with_draws(net, images.to(DEV), labels.to(DEV), rnd.to(DEV), noise.to(DEV), md, mae_loss_coef=0.1)
+        loss.mean().backward()
+        pl = eng.plan(B, True, True, Lv)
+        plan_ids.append(id(pl))
+        pl.fwd.marker = 'patched'  # stands for bench.py's GemmTimer.wrap instrumentation
+        assert pl.Lv == Lv and pl.L == 192
+        mdict = {k: torch.from_numpy(v) for k, v in O.get_mask_from_noise(g['mask_noise'], ratio).items()}
+        loss_ref, _, grads_ref = O.loss_and_grads(P, cfg, images, labels, rnd, noise, mdict, 0.1)
+        rl = ((loss.detach().cpu() - loss_ref).abs() / loss_ref.abs()).max().item()
+        assert rl <= TOL_LOSS, (Lv, rl)
+        params = dict(net.named_parameters())
+        for k, gr in grads_ref.items():
+            num = (params[k].grad.detach().cpu().double() - gr.double()).norm().item()
+            assert num <= TOL_GRAD * gr.double().norm().item() + 1e-7, f'kept {Lv}: {k}'
+        # other shapes in between: eval forward (unmasked) and a training plan of another bucket
+        net.eval()
+        with torch.no_grad():
+            net(images[:4].to(DEV), torch.ones(4, device=DEV), labels[:4].to(DEV))
+        net.train()
+        md2 = M.get_mask(B, T, 0.5, DEV, noise=mnoise.to(DEV))
+        with torch.no_grad():
+            M.Losses['edm']().with_draws(net, images.to(DEV), labels.to(DEV), rnd.to(DEV), noise.to(DEV), md2, mae_loss_coef=0.1)
+    assert len(set(plan_ids)) == 1, 'the 192-row training plan was rebuilt instead of re-used'
+    assert getattr(eng.plan(B, True, True, 179).fwd, 'marker', None) == 'patched'
+    assert len(eng._plans) >= 3

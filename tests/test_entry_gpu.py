@@ -166,7 +166,8 @@ def test_generate_with_vae_decode_writes_images(tmp_path):
     assert im.shape == (256, 256, 3) and im.dtype == np.uint8 and im.std() > 1.0
 
 
-def test_bench_two_ranks_on_one_device():
+@pytest.mark.parametrize('extra', [(), ('--zero1', '--grad-wire', 'bf16')])
+def test_bench_two_ranks_on_one_device(extra):
     """bench.py's N > 1 path end to end (its `world > 1` branches had never executed): launched exactly as
     the driver does (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2 ...`), with the test hook
     MDT_BENCH_ONE_DEVICE=1 putting both ranks on cuda:0 over gloo (RCCL needs one device per rank; the driver's 8-GPU run
@@ -187,7 +188,7 @@ def test_bench_two_ranks_on_one_device():
         env.pop(k, None)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1',
-           '--no-cpu-baseline', '--no-sampler', '--global-batch', '256']
+           '--no-cpu-baseline', '--no-sampler', '--global-batch', '256', *extra]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
@@ -195,7 +196,33 @@ def test_bench_two_ranks_on_one_device():
     rec = json.loads(lines[0])
     assert rec['n_gpus'] == 2 and rec['steps'] == 1 and rec['warmup'] == 1 and rec['scaling'] == 'strong'
     cfg = rec['config']
-    assert cfg['global_batch'] == 256 and cfg['per_gpu_batch'] == 128 and cfg['parallelism'] == 'dp2'
+    assert cfg['global_batch'] == 256 and cfg['per_gpu_batch'] == 128
+    assert cfg['parallelism'] == ('dp2+zero1+bf16grads' if extra else 'dp2')
     assert np.isfinite(rec['mean_loss']) and 0 < rec['mean_loss'] < 100
     assert abs(rec['value'] - 256 / (rec['ms_per_step'] * 1e-3)) <= 0.02 * rec['value']
     assert rec['roofline'] is not None and rec['roofline']['launches'] > 0
+
+
+def test_auto_resume_logger_and_in_loop_eval(tmp_path):
+    """train.py:98-103 (no --ckpt_path: resume from the experiment's newest checkpoint; stdout tee'd into log.txt) and
+    train.py:274-286 (--enable_eval: samples from the EMA weights after a checkpoint)."""
+    import train as T
+    tmp = str(tmp_path)
+    cfg = _cfg(tmp)
+    base = ['--config', cfg, '--results_dir', tmp, '--exp_name', 'r', '--max_num_steps', '3']
+    out = T.train_loop(T.parse(base + ['--enable_eval', '--eval_seeds', '6', '--num_steps', '4', '--cfg_scale', '1.5', '--max_batch_size', '4']))
+    assert out['step'] == 3
+    ev = out['eval']
+    assert ev is not None and ev['n'] == 6 and np.isfinite(ev['mean']) and ev['std'] > 0
+    files = sorted(os.listdir(ev['outdir']))
+    assert files == [f'{s:06d}.npy' for s in range(6)] and 'edm-steps4-ckpt3_cfg1.5' in ev['outdir']
+    z = np.load(os.path.join(ev['outdir'], files[0]))
+    assert z.shape == (4, 32, 32) and z.dtype == np.float64 and np.isfinite(z).all()
+    assert T.get_latest_ckpt(os.path.join(tmp, 'r', 'checkpoints')).endswith('0000003.pt')
+    out2 = T.train_loop(T.parse(base))  # same experiment, no --ckpt_path: continues from step 3
+    assert out2['step'] == 6 and out2['opt'].param_groups[0]['step'] == 6
+    log = open(os.path.join(tmp, 'r', 'log.txt')).read()
+    assert 'Saved checkpoint' in log and 'resuming from the latest checkpoint' in log and 'eval @ step 3' in log
+    assert log.count('Train Steps/Sec') >= 2
+    out3 = T.train_loop(T.parse(base + ['--auto_resume', 'False', '--exp_name', 'r2']))
+    assert out3['step'] == 3

@@ -132,6 +132,23 @@ def test_sampler_matches_reference(golden_dir):
     np.testing.assert_allclose(z2.numpy(), g['z_nocfg'], rtol=1e-4, atol=1e-4)
 
 
+def test_sampler_churn_matches_reference(golden_dir):
+    """The stochastic branch of sample.py:51-53 (S_churn > 0): noise from the reference's per-seed generators, whose
+    state continues from the latent / label draws (generate.py order)."""
+    from maskdit_amd.latents import StackedRandomGenerator
+    g = _load(golden_dir, 's2_sampler_churn.npz')
+    cfg = O.make_cfg('DiT-S/2', img_resolution=32)
+    P = O.init_params(cfg, seed=int(g['seed']), dezero=True)
+    rnd = StackedRandomGenerator('cpu', [int(s) for s in g['seeds']])
+    lat = rnd.randn([len(g['seeds']), 4, 32, 32])
+    cls = rnd.randint(1000, size=[len(g['seeds'])])
+    assert np.array_equal(lat.numpy(), g['latents']) and np.array_equal(cls.numpy(), g['cls'])
+    z = O.edm_sampler(P, cfg, lat, torch.eye(1000)[cls], cfg_scale=float(g['cfg_scale']), num_steps=int(g['num_steps']),
+                      S_churn=float(g['S_churn']), S_min=float(g['S_min']), S_max=float(g['S_max']), S_noise=float(g['S_noise']),
+                      randn_like=rnd.randn_like)
+    np.testing.assert_allclose(z.numpy(), g['z'], rtol=1e-4, atol=1e-4)
+
+
 def test_t_steps_schedule():
     t = O.edm_t_steps(50)
     assert t.dtype == torch.float64 and t.shape == (51,)

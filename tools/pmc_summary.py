@@ -5,8 +5,11 @@ on gfx950 FETCH_SIZE counts 128-byte requests as 64 bytes for wide coalesced rea
 The optional trailing arguments are recorded in out.json: bench.py only reports `roofline.traffic` when they match the
 benchmarked workload."""
 import json
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def per_kernel(db_path, counter):
@@ -17,6 +20,11 @@ def per_kernel(db_path, counter):
     if q is None:
         raise SystemExit(f'unexpected schema: {cols}')
     return {n: (c, v) for n, c, v in db.execute(q, (counter,))}
+
+
+def _source_hash():
+    from maskdit_amd import _lib
+    return _lib.source_hash()
 
 
 def main(fetch_db, write_db, out_json, out_txt, model=None, resolution=None, micro_batch=None, command=None):
@@ -39,7 +47,7 @@ def main(fetch_db, write_db, out_json, out_txt, model=None, resolution=None, mic
     json.dump({'kernel': 'gemm_nt8_kernel + gemm_nt_kernel (all mdt_gemm_nt launches)', 'launches': n,
                'hbm_bytes_per_launch': round(tot / max(n, 1)),
                'model': model, 'resolution': int(resolution) if resolution else None,
-               'micro_batch': int(micro_batch) if micro_batch else None, 'command': command,
+               'micro_batch': int(micro_batch) if micro_batch else None, 'command': command, 'source_hash': _source_hash(),
                'note': 'read side = FETCH_SIZE x 2 (gfx950 correction), write side = WRITE_SIZE (uncalibrated)'}, open(out_json, 'w'), indent=1)
     print('\n'.join(lines[:14]))
 

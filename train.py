@@ -19,6 +19,8 @@ from __future__ import annotations
 import argparse
 import copy
 import os
+import re
+import sys
 import time
 
 import torch
@@ -37,6 +39,91 @@ def strip_compile_prefix(sd):
     return {k.replace('_orig_mod.', ''): v for k, v in sd.items()}
 
 
+def get_latest_ckpt(ckpt_dir):
+    """utils.py:22-34: the highest-numbered `<step>.pt` of a checkpoint directory, or None."""
+    best = -1
+    if os.path.isdir(ckpt_dir):
+        for f in os.listdir(ckpt_dir):
+            m = re.fullmatch(r'(\d+)\.pt', f)
+            if m:
+                best = max(best, int(m.group(1)))
+    return os.path.join(ckpt_dir, f'{best:07d}.pt') if best >= 0 else None
+
+
+class Logger:
+    """utils.py:169-225: tee of stdout / stderr into `<experiment>/log.txt` (rank 0), flushed on every write."""
+
+    def __init__(self, file_name, file_mode='a+'):
+        self.file = open(file_name, file_mode)
+        self.stdout, self.stderr = sys.stdout, sys.stderr
+        sys.stdout = sys.stderr = self
+
+    def write(self, text):
+        if text:
+            self.file.write(text)
+            self.stdout.write(text)
+            self.flush()
+
+    def flush(self):
+        self.file.flush()
+        self.stdout.flush()
+
+    def close(self):
+        self.flush()
+        if sys.stdout is self:
+            sys.stdout = self.stdout
+        if sys.stderr is self:
+            sys.stderr = self.stderr
+        self.file.close()
+
+
+def evaluate_in_loop(args, cfg, ema, dev, rank, world, exp_dir, step):
+    """train.py:274-286 (`--enable_eval`): after a checkpoint, every rank generates its share of `eval_seeds` from the
+    EMA weights with the hipGraph sampler (generate_with_net, sample.py:230-296) into
+    `<experiment>/fid/edm-steps<N>-ckpt<step>_cfg<s>/`.  The FID number itself needs the Inception network pickle,
+    which is not available offline: when `--ref_path` points at reference statistics AND an evaluator is
+    importable it is computed, otherwise the samples are left for an offline evaluator and the hook reports their
+    latent statistics."""
+    import numpy as np
+    outdir = os.path.join(exp_dir, 'fid', f'edm-steps{args.num_steps}-ckpt{step}_cfg{args.cfg_scale}')
+    os.makedirs(outdir, exist_ok=True)
+    was_training = ema.training
+    ema.eval()
+    t0, n, stats = time.time(), 0, torch.zeros(2, device=dev, dtype=torch.float64)
+    for seeds in M.seed_batches(list(range(args.eval_seeds)), args.max_batch_size, rank, world):
+        if not seeds:
+            continue
+        rnd = M.StackedRandomGenerator(dev, seeds)
+        lat = rnd.randn([len(seeds), ema.img_channels, ema.img_resolution, ema.img_resolution], device=dev)
+        lab = torch.eye(ema.num_classes, device=dev)[rnd.randint(ema.num_classes, size=[len(seeds)], device=dev)]
+        z = M.edm_sampler(ema, lat, lab, cfg_scale=args.cfg_scale, randn_like=rnd.randn_like, num_steps=args.num_steps)
+        stats += torch.stack([z.sum(), (z * z).sum()])
+        for sd, zi in zip(seeds, z.cpu().numpy()):
+            np.save(os.path.join(outdir, f'{sd:06d}.npy'), zi)
+        n += len(seeds)
+    ema.train(was_training)
+    cnt = torch.tensor([float(n)], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(stats)
+        dist.all_reduce(cnt)
+        dist.barrier()
+    numel = cnt.item() * ema.img_channels * ema.img_resolution ** 2
+    mean = stats[0].item() / max(numel, 1)
+    std = max(stats[1].item() / max(numel, 1) - mean * mean, 0.0) ** 0.5
+    fid = None
+    if args.ref_path:
+        try:
+            from fid import calc  # the reference's evaluator (fid.py), when the user has it + the Inception pickle
+            fid = calc(outdir, args.ref_path, args.eval_seeds, args.global_seed, 64)
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                print(f'eval: FID evaluator unavailable ({type(e).__name__}: {e}); samples kept in {outdir}', flush=True)
+    if rank == 0:
+        print(f'eval @ step {step}: {int(cnt.item())} samples, {args.num_steps} steps, cfg={args.cfg_scale}, latent mean {mean:+.4f} std {std:.4f}, '
+              f'time {time.time() - t0:.1f} s' + (f', fid: {fid}' if fid is not None else ''), flush=True)
+    return {'outdir': outdir, 'n': int(cnt.item()), 'mean': mean, 'std': std, 'fid': fid}
+
+
 def parse(argv=None):
     ap = argparse.ArgumentParser('training parameters')
     ap.add_argument('--config', required=True)
@@ -47,6 +134,15 @@ def parse(argv=None):
     ap.add_argument('--global_seed', type=int, default=0)
     ap.add_argument('--max_num_steps', type=int, default=None)
     ap.add_argument('--data_path', default=None, help='override data.root (wds: shard dir / glob; lmdb: dataset dir)')
+    ap.add_argument('--use_ckpt_path', type=str2bool, default=True)     # train.py:87: with --ckpt_path, keep writing into ITS experiment dir
+    ap.add_argument('--auto_resume', type=str2bool, default=True)       # train.py:98-99: no --ckpt_path -> newest checkpoint of the exp dir
+    # in-loop evaluation (train.py:274-286, args of train.py:318-331)
+    ap.add_argument('--enable_eval', action='store_true')
+    ap.add_argument('--eval_seeds', type=int, default=64, help='samples generated per evaluation (reference: seeds 0-49999)')
+    ap.add_argument('--max_batch_size', type=int, default=64)
+    ap.add_argument('--num_steps', type=int, default=40)
+    ap.add_argument('--cfg_scale', type=float, default=None)
+    ap.add_argument('--ref_path', default=None)
     return ap.parse_args(argv)
 
 
@@ -95,7 +191,31 @@ def train_loop(args):
     ema = copy.deepcopy(net).eval()
     for p in ema.parameters():
         p.requires_grad_(False)
-    opt = M.FusedAdam(net.parameters(), lr=tc.lr, adam_w_mode=True, weight_decay=0)
+    # experiment directory (train.py:85-103): with --ckpt_path (and use_ckpt_path) keep writing into that checkpoint's
+    # experiment; otherwise <results_dir>/<exp_name>, resuming from its newest checkpoint if there is one
+    resumed = False
+    if args.ckpt_path and args.use_ckpt_path and os.path.basename(os.path.dirname(os.path.abspath(args.ckpt_path))) == 'checkpoints':
+        exp_dir = os.path.dirname(os.path.dirname(os.path.abspath(args.ckpt_path)))
+    else:
+        exp_dir = os.path.join(args.results_dir, args.exp_name)
+        if args.ckpt_path is None and args.auto_resume:
+            args.ckpt_path = get_latest_ckpt(os.path.join(exp_dir, 'checkpoints'))
+            resumed = args.ckpt_path is not None
+    logger = None
+    if rank == 0:
+        os.makedirs(os.path.join(exp_dir, 'checkpoints'), exist_ok=True)
+        logger = Logger(os.path.join(exp_dir, 'log.txt'))
+        print(f'Experiment directory created at {exp_dir}', flush=True)
+        if resumed:
+            print(f'resuming from the latest checkpoint {args.ckpt_path}', flush=True)
+    # data parallelism first: the sharded optimizer (train.zero1) needs the wrapper's reducer
+    wire = str(tc.get('grad_wire', 'fp32')).lower()
+    model = M.DataParallel(net, grad_wire_dtype=torch.bfloat16 if wire in ('bf16', 'bfloat16') else None) if world > 1 else net
+    zero1 = bool(tc.get('zero1', False)) and world > 1
+    if zero1:  # optimizer state / optimizer + EMA stream sharded over the ranks (maskdit_amd/zero.py)
+        opt = M.ShardedFusedAdam(net.parameters(), data_parallel=model, lr=tc.lr, adam_w_mode=True, weight_decay=0)
+    else:
+        opt = M.FusedAdam(net.parameters(), lr=tc.lr, adam_w_mode=True, weight_decay=0)
     step0 = 0
     if args.ckpt_path:  # train.py:147-162
         ck = torch.load(args.ckpt_path, map_location='cpu', weights_only=False)
@@ -109,7 +229,10 @@ def train_loop(args):
     else:
         M.update_ema(ema, net, decay=0)  # train.py:184-188: only a FRESH run copies the model into the EMA
     opt.fuse_ema(ema, 0.9999)
-    model = M.DataParallel(net) if world > 1 else net
+    if world > 1 and args.ckpt_path:  # the checkpoint was loaded after DataParallel's construction-time broadcast
+        dist.broadcast(net.engine().P, src=0)
+        dist.broadcast(ema.engine().P, src=0)
+        net.engine().shadows_dirty = ema.engine().shadows_dirty = True
     net.train()
     loss_fn = M.Losses['edm']()
     mask_ratio_fn = get_mask_ratio_fn(mc.get('mask_ratio_fn', 'constant'), mc.mask_ratio, mc.get('mask_ratio_min', 0))
@@ -117,15 +240,14 @@ def train_loop(args):
     mb = tc.batchsize
     global_batch = mb * accum * world
     max_steps = args.max_num_steps or tc.get('max_num_steps', 100)
-    exp_dir = os.path.join(args.results_dir, args.exp_name)
     if rank == 0:
-        os.makedirs(os.path.join(exp_dir, 'checkpoints'), exist_ok=True)
         print(f'{mc.model_type} params {sum(p.numel() for p in net.parameters()):,}  global batch {global_batch} '
-              f'({world} GPU x {mb} x accum {accum})  steps {step0} -> {step0 + max_steps}', flush=True)
+              f'({world} GPU x {mb} x accum {accum})  steps {step0} -> {step0 + max_steps}'
+              + ('  [ZeRO-1]' if zero1 else '') + (f'  [gradient wire {wire}]' if world > 1 else ''), flush=True)
 
     batches = make_batches(cfg, args, dev, rank, world, mb * accum)
     step, log_steps, running = step0, 0, torch.zeros((), device=dev)
-    last_loss = None
+    last_loss = last_eval = None
     t0 = time.time()
     for mom, cls in batches:
         x = M.sample(mom)                                      # train.py:203
@@ -166,16 +288,32 @@ def train_loop(args):
                       f'img/s: {sps * global_batch:.1f}, mem: {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB', flush=True)
             running.zero_()
             log_steps, t0 = 0, time.time()
-        if step % cfg.log.ckpt_every == 0 and step > step0 and rank == 0:  # train.py:259-271
-            torch.save({'model': net.state_dict(), 'ema': ema.state_dict(), 'opt': opt.state_dict(), 'args': vars(args)},
-                       os.path.join(exp_dir, 'checkpoints', f'{step:07d}.pt'))
+        if step % cfg.log.ckpt_every == 0 and step > step0:            # train.py:259-271
+            if zero1:
+                opt.consolidate()  # COLLECTIVE: moments + EMA gathered so that rank 0 alone can save
+            if rank == 0:
+                torch.save({'model': net.state_dict(), 'ema': ema.state_dict(), 'opt': opt.state_dict(), 'args': vars(args)},
+                           os.path.join(exp_dir, 'checkpoints', f'{step:07d}.pt'))
+                print(f'Saved checkpoint to {os.path.join(exp_dir, "checkpoints", f"{step:07d}.pt")}', flush=True)
+            if world > 1:
+                dist.barrier()
+            if args.enable_eval:                                       # train.py:274-286
+                if zero1:
+                    opt.sync_ema()
+                last_eval = evaluate_in_loop(args, cfg, ema, dev, rank, world, exp_dir, step)
+                t0, log_steps = time.time(), 0
+                running.zero_()
         if step >= step0 + max_steps:                          # train.py:236: max_num_steps MORE steps
             break
     if hasattr(batches, 'close'):
         batches.close()
     if world > 1:
         dist.barrier()
-    return {'net': net, 'ema': ema, 'opt': opt, 'step': step, 'loss': last_loss, 'exp_dir': exp_dir}
+    if zero1:
+        opt.sync_ema()
+    if logger is not None:
+        logger.close()
+    return {'net': net, 'ema': ema, 'opt': opt, 'step': step, 'loss': last_loss, 'exp_dir': exp_dir, 'eval': last_eval}
 
 
 def main():
