@@ -294,7 +294,7 @@ extern "C" int mdt_gemm_nt(const mdt_gemm_nt_args* a, mdt_stream_t stream) {
   if (a->epi == MDT_EPI_DGELU || a->epi == MDT_EPI_DSILU) nt8_ok = nt8_ok && a->ldaux % 4 == 0 && ((uintptr_t)a->aux & 7) == 0;
   if (nt8_ok) {
     if (mdt_get_tuning_int(MDT_TUNE_NT8_SKIP_EPILOGUE)) p.epi |= 0x100;
-    if (mdt_get_tuning_int(MDT_TUNE_NT8_STAGGER)) p.epi |= 0x200;
+    if (const int stg = mdt_get_tuning_int(MDT_TUNE_NT8_STAGGER)) p.epi |= 0x200 | ((stg < 255 ? stg : 255) << 16);
     const bool can8 = (a->M % 256 == 0);
     const int cus = nt8_num_cus();
     // column tile: 256 (NF = 4) where the epilogue class has it, else 192, else 128; "nt8_nf3" prefers 192-column

@@ -44,6 +44,11 @@
 #define NT8_ZERO_ROW 1024
 static __device__ float nt8_zero_row[NT8_ZERO_ROW + 64];  // zero-initialised; one copy per translation unit
 
+// timing stamps of the experiment kernels (SCHED bit 9; tools/nt8_stamps.py): [tile][event] shader-clock values of wave 0
+// of workgroup 0 -- 0 tile start (after the tile-top wait + barrier), 1 K loop done, 2 next tile's LDS-DMA issued,
+// 3 epilogue's last store issued
+static __device__ unsigned long long nt8_stamps[2 * 64 * 4];  // [wave 0 | last wave]
+
 namespace nt8 {
 
 enum { E_PLAIN = 0, E_F32 = 1, E_ACT = 2, E_GATE = 3, E_DACT = 4,
@@ -128,6 +133,11 @@ template <int NF> __device__ __forceinline__ void store_band_bf16(char* ub, unsi
   }
   if (NF & 1) *(uint2*)(ub + opaque(lo_tail) + 32 * (NF - 1)) = make_uint2(lo[NF - 1], hi[NF - 1]);
 }
+// (measured and dropped, round 3: whole-128-byte-line stores for NF = 4 -- the second 64-byte piece of a row rotated by 8
+// lanes with DPP row_ror:8 so that one instruction writes 8 rows x 128 B.  tools/micro/store_bench.hip: a lone CU writes
+// 64-byte segments at <= 24 GB/s and whole lines at >= 51 GB/s, but inside this epilogue nothing moved (1156 vs 1164 us at
+// 256 CUs, 4.5 vs 4.75 us per tile at 128 CUs, with or without a half-period workgroup stagger: gpurun_out/r3/nt8_lines2.log)
+// -- with every CU in its epilogue at once the stores run at the chip's HBM write rate, 5-6 TB/s.)
 // lane byte offsets into a bf16 [rows, ld] array for store_band_bf16 (fr = lane & 15, fg = lane >> 4)
 __device__ __forceinline__ unsigned bf16_pair_offset(int fr, int fg, int ld) {
   return (unsigned)(fr * ld + ((fg & 1) ? 16 + 4 * (fg - 1) : 4 * fg)) * 2u;
@@ -159,7 +169,9 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
   constexpr int QLAST = 4 * NF - 1;
   constexpr int QA = SP == 8 ? QLAST : SP == 9 ? (9 < QLAST ? 9 : QLAST) : 4;
   constexpr int QB = SP == 8 ? QLAST : SP == 9 ? QLAST : (8 < QLAST ? 8 : QLAST);
-  constexpr bool FJ = NF == 4 && (SP == 5 || SP == 11);  // (measured and dropped: non-temporal epilogue stores -- the plain-bf16 epilogue gets 8-17 % SLOWER, gpurun_out/r3/sched4.log)
+  constexpr bool FJ = NF == 4 && (SP == 5 || SP == 11);
+  constexpr bool XPF = !(SCHED & 1024) && E != E_TRK;  // cross-tile prefetch inside the last K-tile pair (bit 10 = the round-2 burst, A/B runs)
+  // (measured and dropped: non-temporal epilogue stores -- the plain-bf16 epilogue gets 8-17 % SLOWER, gpurun_out/r3/sched4.log)
   constexpr bool X_NODMA = (SCHED & 32) != 0, X_NOREAD = (SCHED & 64) != 0, X_NOBAR = (SCHED & 128) != 0;
   constexpr int BN8 = 64 * NF;
   constexpr int BM8 = 128 * WR;
@@ -176,6 +188,12 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
+  constexpr bool STAMPS = (SCHED & 512) != 0;
+  int stamp_tile = 0;
+  auto stamp = [&](int ev) {
+    if (STAMPS && blockIdx.x == 0 && (tid == 0 || tid == 256 * WR - 64) && stamp_tile < 64)
+      nt8_stamps[(tid ? 256 : 0) + stamp_tile * 4 + ev] = __builtin_readcyclecounter();
+  };
   // the two waves of a SIMD are w and w + WAVES/2 (a workgroup's waves go round the four SIMDs): "first half"
   // = the first wave of each SIMD
   const bool first_half = wave < 2 * WR;
@@ -273,7 +291,8 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
   // loops of the other half instead of all 256 CUs bursting in lock-step.
   if ((p.epi & 0x200) && (WR == 1 ? (blockIdx.x >= (gridDim.x >> 1)) : ((blockIdx.x & 8) != 0))) {
     // 4-wave form: the second workgroup of each CU (dispatched in the second half of the grid)
-    const int naps = ((p.K >> 6) * 1700 + 6000) >> 13;  // ~0.7 us per K-tile + half an epilogue, in 8192-cycle naps
+    // delay in 8192-cycle naps: (epi >> 16) & 0xff when given (mdt_set_tuning nt8_stagger = naps), else about half a tile period
+    const int naps = ((p.epi >> 16) & 0xff) > 1 ? ((p.epi >> 16) & 0xff) : (((p.K >> 6) * 1500 + 8000) >> 14);
     for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
   }
   // ---- prologue of the first tile: K-tiles 0 and 1 in steady-state issue order
@@ -282,6 +301,7 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
 #pragma unroll
   for (int ph = 0; ph < 4; ++ph) issue(1, 1, ph);
 
+  static_assert(SP == 5 || (SP >= 8 && SP <= 10), "only the fine-interleaved phase forms are compiled");
   if (SP == 10 && !first_half) __builtin_amdgcn_s_setprio(1);  // static priority for the second wave of each SIMD
   for (;;) {  // persistent tile loop
 #pragma unroll
@@ -293,6 +313,7 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
   wait_vm_lgkm<0>();
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  stamp(0);
   // (returns in order right behind the two prefetched K-tiles; the counted waits of the K loop stay valid --
   // they only become marginally stricter for the first phases)
   if constexpr (EARLY_BIAS) load_bias(n0 + wc * WN);
@@ -314,7 +335,7 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
   //   2  every wave issues its LDS-DMA after the cluster                                                  1362 / 1450
   //   3  every wave issues its LDS-DMA between the ks = 0 and ks = 1 halves of the cluster                (+1..4 %)
   //   4  waves 0-3 as 0; waves 4-7 LDS-DMA in the middle                                                  (-5 %)
-  //   5  ONE MEMORY INSTRUCTION PINNED BEHIND EACH MFMA (NT8_FINE), no setprio: THE DEFAULT               1412 / 1512
+  //   5  ONE MEMORY INSTRUCTION PINNED BEHIND EACH MFMA (NT8_FINE), no setprio: THE PRODUCT FORM         1412 / 1512
   //   6  as 1, and waves 4-7 also issue their fragment reads in the middle of the cluster                 (-3 %)
   //   7  as 0 without s_setprio                                                                           1316 / 1423
   //   8 / 9 / 10  variations of 5 (LDS-DMA behind the last MFMA; reads behind every second MFMA; static s_setprio 1
@@ -325,38 +346,17 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
   // neither DMA nor reads 1836, MFMAs alone 1955-2054 (= the clock-limited matrix rate): what is left is the cost of
   // the memory instructions themselves (~14 matrix-pipe cycles per ds_read_b128, ~35 per LDS-DMA), not the barriers.
   // The counted waits are the same for every variant: per wave the ORDER of (issue, wait) events is unchanged.
-#define NT8_READS(DRAIN)                                                                              \
-      if (ph < 3) {                                                                                   \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                              \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
-          Ar[(ph + 1) & 1][i][ks] = *(const bf16x8*)(cur + a_off[ks] + (2 * (ph + 1) + i) * 2048);    \
-      } else if (!(DRAIN && half == 1)) {                                                             \
-        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                            \
-          _Pragma("unroll") for (int i = 0; i < 2; ++i)                                               \
-            Ar[0][i][ks] = *(const bf16x8*)(nxt + a_off[ks] + i * 2048);                              \
-          if (BDB) {                                                                                  \
-            _Pragma("unroll") for (int j = 0; j < NF; ++j)                                            \
-              Br[BDB ? (half ^ 1) : 0][j][ks] = *(const bf16x8*)(nxt + b_off[ks] + j * 2048);         \
-          }                                                                                           \
-        }                                                                                             \
-      }
-#define NT8_DMA(DRAIN)                                                                                \
-      if (!DRAIN) issue(half, kt + half + 2, ph);                                                     \
-      if (E == E_TRK && !DRAIN) trickle((kt + half) * 4 + ph, acc[2 * ph][0]);
-#define NT8_MFMAS(DRAIN, KS)                                                                          \
-      {                                                                                               \
-        constexpr int ks = KS;                                                                        \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                 \
-        _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                \
-          acc[2 * ph + i][j] = mfma16(Br[BDB ? half : 0][j][ks], Ar[ph & 1][i][ks], acc[2 * ph + i][j]); \
-        if (!BDB && ph == 3 && !(DRAIN && half == 1)) {                                               \
-          _Pragma("unroll") for (int j = 0; j < NF; ++j)                                              \
-            Br[0][j][ks] = *(const bf16x8*)(nxt + b_off[ks] + j * 2048);                              \
-        }                                                                                             \
-      }
-  // SP 5: one memory instruction pinned behind every MFMA (the reads of the next phase first, the A piece of the
-  // LDS-DMA refill after MFMA 4, the B piece after MFMA 8), no s_setprio
-#define NT8_FINE(DRAIN)                                                                               \
+  // Only form 5 (and its 8 / 9 / 10 parameterisations) is compiled since the cross-tile prefetch went in; the clustered
+  // forms live in the round-3 history (git: 38727ef).
+  // One phase (NT8_FINE): MFMA q is followed by memory instruction q -- the ds_reads of the next phase's fragments
+  // first, then the A piece / the B piece of the LDS-DMA refill (QA / QB).  MODE: 0 = steady state (refill with K-tile
+  // kt + 2 of THIS output tile); 1 = the last K-tile pair of a tile that has a successor: the refills fetch K-tiles 0 / 1
+  // of the workgroup's NEXT tile, so the K loop's issue pattern -- and its counted waits -- simply continue across the
+  // tile boundary (round 3; rounds 1-2 issued those 14-16 LDS-DMAs per wave as ONE burst after the K loop: the CU's
+  // vector-memory path takes ~48 clocks per wave-instruction there, tools/nt8_stamps.py measured 7000 clocks = 15 % of
+  // a K = 1152 tile for the last wave to get its burst out before it could start its epilogue); 2 = the last pair of
+  // the workgroup's last tile (nothing to fetch, draining waits).
+#define NT8_FINE(MODE)                                                                                \
       _Pragma("unroll") for (int q = 0; q < 4 * NF; ++q) {                                            \
         /* MFMA order: (ks, i, j); FJ (NF = 4, last phase): the ks = 1 half runs (j, i) so that B[j][1] dies early */ \
         const bool jm = FJ && ph == 3 && q >= 2 * NF;                                                 \
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
             const int r = q / RS;                                                                     \
             Ar[(ph + 1) & 1][r & 1][r >> 1] = *(const bf16x8*)(cur + a_off[r >> 1] + (2 * (ph + 1) + (r & 1)) * 2048); \
           }                                                                                           \
-        } else if (!(DRAIN && half == 1)) {                                                           \
+        } else if (!(MODE != 0 && half == 1)) {                                                       \
           if (q < 4) Ar[0][q & 1][q >> 1] = *(const bf16x8*)(nxt + a_off[q >> 1] + (q & 1) * 2048);   \
           else if (BDB && q - 4 < 2 * NF)                                                             \
             Br[BDB ? (half ^ 1) : 0][(q - 4) % NF][(q - 4) / NF] = *(const bf16x8*)(nxt + b_off[(q - 4) / NF] + ((q - 4) % NF) * 2048); \
@@ -379,43 +379,27 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
           else if (!BDB && FJ && q > 2 * NF && (q & 1))                /* B[j][1] dies at q = 2 NF + 2 j + 1 */ \
             Br[0][(q - 2 * NF) >> 1][1] = *(const bf16x8*)(nxt + b_off[1] + ((q - 2 * NF) >> 1) * 2048); \
         }                                                                                             \
-        if (!DRAIN && !X_NODMA && q == (ph < 3 ? QA : 3 * NF)) issue(half, kt + half + 2, ph, 1);     \
-        if (!DRAIN && !X_NODMA && q == (ph < 3 ? QB : 4 * NF - 1)) issue(half, kt + half + 2, ph, 2);  \
+        if (MODE != 2 && !X_NODMA && q == (ph < 3 ? QA : 3 * NF)) {                                   \
+          if (MODE == 0) issue(half, kt + half + 2, ph, 1); else issue_next(half, ph, 1);             \
+        }                                                                                             \
+        if (MODE != 2 && !X_NODMA && q == (ph < 3 ? QB : 4 * NF - 1)) {                               \
+          if (MODE == 0) issue(half, kt + half + 2, ph, 2); else issue_next(half, ph, 2);             \
+        }                                                                                             \
+        if (E == E_TRK && MODE == 0 && q == 2) trickle((kt + half) * 4 + ph, acc[2 * ph][0]);         \
         __builtin_amdgcn_sched_barrier(0);                                                            \
       }                                                                                               \
-      if (!BDB && !FJ && ph == 3 && !(DRAIN && half == 1) && !X_NOREAD) {                             \
+      if (!BDB && !FJ && ph == 3 && !(MODE != 0 && half == 1) && !X_NOREAD) {                         \
         _Pragma("unroll") for (int j = 0; j < NF; ++j)                                                \
           Br[0][j][1] = *(const bf16x8*)(nxt + b_off[1] + j * 2048);                                  \
       }
-#define PAIR_BODY(DRAIN)                                                                              \
+#define PAIR_BODY(MODE)                                                                               \
   _Pragma("unroll") for (int half = 0; half < 2; ++half) {                                            \
     const char* cur = smem + half * STAGE;                                                            \
     const char* nxt = smem + (half ^ 1) * STAGE;                                                      \
     _Pragma("unroll") for (int ph = 0; ph < 4; ++ph) {                                                \
-      if (SP == 5 || SP >= 8) { NT8_FINE(DRAIN) } else {                                                         \
-      /* (1) prefetch the fragments of the next phase */                                              \
-      if (SP != 6 || first_half) { NT8_READS(DRAIN) }                                                 \
-      /* (2) refill the slot whose reads retired before the previous barrier */                       \
-      if (SP == 0 || SP == 7 || ((SP == 1 || SP == 4 || SP == 6) && first_half)) { NT8_DMA(DRAIN) } \
-      /* (3) this phase's MFMAs */                                                                    \
-      if (SP != 7) __builtin_amdgcn_s_setprio(1);                                          \
-      NT8_MFMAS(DRAIN, 0)                                                                             \
-      if (SP == 3 || (SP == 4 && !first_half)) {                                                      \
-        __builtin_amdgcn_s_setprio(0);                                                                \
-        NT8_DMA(DRAIN)                                                                                \
-        __builtin_amdgcn_s_setprio(1);                                                                \
-      }                                                                                               \
-      if (SP == 6 && !first_half) {                                                                   \
-        __builtin_amdgcn_s_setprio(0);                                                                \
-        NT8_READS(DRAIN)                                                                              \
-        __builtin_amdgcn_s_setprio(1);                                                                \
-      }                                                                                               \
-      NT8_MFMAS(DRAIN, 1)                                                                             \
-      if (SP != 7) __builtin_amdgcn_s_setprio(0);                                          \
-      if (SP == 2 || ((SP == 1 || SP == 6) && !first_half)) { NT8_DMA(DRAIN) }                        \
-      }                                                                                               \
-      /* (4) publish: my share of the next phase's data has landed, my LDS reads have retired */      \
-      if (DRAIN) {                                                                                    \
+      NT8_FINE(MODE)                                                                                  \
+      /* publish: my share of the next phase's data has landed, my LDS reads have retired */          \
+      if (MODE == 2) {                                                                                \
         if (half == 0 && ph == 0) wait_vm_lgkm<drain_count(0, NF, RPP)>();                            \
         else if (half == 0 && ph == 1) wait_vm_lgkm<drain_count(1, NF, RPP)>();                       \
         else if (half == 0 && ph == 2) wait_vm_lgkm<drain_count(2, NF, RPP)>();                       \
@@ -433,18 +417,12 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
     }                                                                                                 \
   }
 
+  // K-tile `stage` (0 / 1) of the NEXT tile (a_u / b_u already point at it when the last pair runs)
+  auto issue_next = [&](int stage, int ph, int part) { issue(stage, stage, ph, part); };
   int kt = 0;
-  for (; kt + 2 < nk; kt += 2) { PAIR_BODY(false) }
-  { PAIR_BODY(true) }
-#undef PAIR_BODY
-#undef NT8_READS
-#undef NT8_DMA
-#undef NT8_MFMAS
-#undef NT8_FINE
-
-  // ---- next tile: put its first two K-tiles in flight (every LDS read of this tile retired
-  // before the last barrier), then run this tile's epilogue underneath them
-  const int em0 = m0 + wr * 128, en0 = n0 + wc * WN;  // origin of this wave's 128 x WN block
+  for (; kt + 2 < nk; kt += 2) { PAIR_BODY(0) }
+  // the workgroup's next output tile (if any): its first two K-tiles are fetched by the refills of the last pair
+  const int em0 = m0 + wr * 128, en0 = n0 + wc * WN;  // origin of this wave's 128 x WN block of the CURRENT tile
   vt += gridDim.x;
   const bool more = vt < ntiles;
   if (more) {
@@ -453,18 +431,32 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
     n0 = tn * BN8;
     a_u = (const char*)(p.A + (long)(m0 + a_row0) * p.lda);
     b_u = (const char*)(p.B + (long)(n0 + 8 * wave) * p.ldb);
+  }
+  // (a workgroup's LAST tile re-fetches its own first two K-tiles into the freed slots instead of branching to a
+  // draining variant: the steady-state waits stay valid, nothing reads those slots again, and a second copy of the
+  // unrolled pair behind a run-time branch made hipcc spill 130-390 registers at the join)
+  if constexpr (XPF) { PAIR_BODY(1) } else { PAIR_BODY(2) }
+#undef PAIR_BODY
+#undef NT8_FINE
+  stamp(1);
+  if (!XPF && more) {  // (rounds 1-2: the next tile's first two K-tiles as one burst after the K loop)
 #pragma unroll
     for (int ph = 0; ph < 4; ++ph) issue(0, 0, ph);
 #pragma unroll
     for (int ph = 0; ph < 4; ++ph) issue(1, 1, ph);
   }
+  stamp(2);
+
 
   if ((p.epi & 0x100) || E == E_TRK) {  // benchmarking aid (mdt_set_tuning "nt8_skip_epilogue"): main loop only
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < NF; ++j) asm volatile("" ::"v"(acc[i][j]));
-    if (!more) break;
+    if (!more) {
+      wait_vm_lgkm<0>();
+      break;
+    }
     continue;
   }
 
@@ -640,7 +632,12 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
     if (act == MDT_EPI_DGELU) { if (p.colsum) body(T{}, T{}); else body(F{}, T{}); }
     else { if (p.colsum) body(T{}, F{}); else body(F{}, F{}); }
   }
-  if (!more) break;
+  stamp(3);
+  ++stamp_tile;
+  if (!more) {
+    wait_vm_lgkm<0>();  // the dummy refills of the last pair must have landed before the workgroup's LDS is released
+    break;
+  }
   }  // persistent tile loop
 }
 

@@ -19,7 +19,7 @@ def main():
     ap.add_argument('--iters', type=int, default=4)
     ap.add_argument('--rounds', type=int, default=3)
     ap.add_argument('--kloop-only', action='store_true')
-    ap.add_argument('--scheds', type=str, default='0,100,16,2,7')
+    ap.add_argument('--scheds', type=str, default='0,1029')
     args = ap.parse_args()
     L = _lib.lib()
     dev = 'cuda'
