@@ -417,6 +417,10 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
     }                                                                                                 \
   }
 
+  // (measured and dropped, round 3: leaving the epilogue's stores in flight across the tile boundary -- tile-top
+  // vmcnt(#stores) and the first six phases' counts raised by the same number.  With an exact store count it changes
+  // nothing (889 vs 894 us qkv forward, gpurun_out/r3/sched7.log): what the tile-top wait waits for is the next tile's
+  // second K-tile, fetched during the last phases of the K loop, not the store acknowledgements.)
   // K-tile `stage` (0 / 1) of the NEXT tile (a_u / b_u already point at it when the last pair runs)
   auto issue_next = [&](int stage, int ph, int part) { issue(stage, stage, ph, part); };
   int kt = 0;
