@@ -30,6 +30,59 @@ struct AttnCfg {
   static constexpr int TILE_BYTES = 64 * PITCH;
 };
 
+// ---- row stores.  An accumulator row = NFRAG fragments, this lane holds 4 consecutive columns (16 f + 4 g ..) of each.
+// Fragment pairs whose 32 columns lie inside HD are exchanged between the odd and even 16-lane rows with
+// v_permlane16_swap (as gemm_nt8's epilogue does) so that every lane stores 8 consecutive columns = ONE 16-byte store
+// instead of two 8-byte ones; the remaining fragments go out as masked 8-byte stores.  8-byte vector-memory accesses run
+// at 0.54-0.70 of the 16-byte rate and the backward kernels are store-issue bound (15 -> 9 stores per wave and item at hd 72).
+template <int HD> struct AttnRow {
+  static constexpr int NFRAG = AttnCfg<HD>::NFRAG;
+  static constexpr int NP = (NFRAG / 2 < HD / 32) ? NFRAG / 2 : HD / 32;  // full pairs
+  static constexpr int NT = NFRAG - 2 * NP;                                // single fragments behind them
+  uint4 pr[NP > 0 ? NP : 1];
+  uint2 tl[NT > 0 ? NT : 1];
+};
+__device__ __forceinline__ unsigned attn_pack2(float a, float b) {
+  bf16x2 t;
+  t[0] = f2bf(a);
+  t[1] = f2bf(b);
+  return __builtin_bit_cast(unsigned, t);
+}
+template <int HD> __device__ __forceinline__ void attn_pack_row(AttnRow<HD>& r, const f32x4* v, float mul = 1.f) {
+  using R = AttnRow<HD>;
+#pragma unroll
+  for (int q = 0; q < R::NP; ++q) {
+    const f32x4 x = v[2 * q] * mul, y = v[2 * q + 1] * mul;
+    auto a = __builtin_amdgcn_permlane16_swap(attn_pack2(x[0], x[1]), attn_pack2(y[0], y[1]), false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(attn_pack2(x[2], x[3]), attn_pack2(y[2], y[3]), false, false);
+    r.pr[q] = make_uint4(a[0], b[0], a[1], b[1]);
+  }
+#pragma unroll
+  for (int t = 0; t < R::NT; ++t) {
+    const f32x4 x = v[2 * R::NP + t] * mul;
+    r.tl[t] = make_uint2(attn_pack2(x[0], x[1]), attn_pack2(x[2], x[3]));
+  }
+}
+// empty use of a row's store-data registers: extends their live range past the point where the stores that read them
+// are old enough for a cheap counted wait (see attn_bwd_item_math)
+template <int HD> __device__ __forceinline__ void attn_keep_alive(const AttnRow<HD>& r) {
+#pragma unroll
+  for (int q = 0; q < AttnRow<HD>::NP; ++q) asm volatile("" ::"v"(r.pr[q].x), "v"(r.pr[q].y), "v"(r.pr[q].z), "v"(r.pr[q].w));
+#pragma unroll
+  for (int t = 0; t < AttnRow<HD>::NT; ++t) asm volatile("" ::"v"(r.tl[t].x), "v"(r.tl[t].y));
+}
+template <int HD> __device__ __forceinline__ void attn_store_row(bf16* row, int g, const AttnRow<HD>& r) {
+  using R = AttnRow<HD>;
+  const int pc = (g & 1) ? 16 + 4 * (g - 1) : 4 * g;  // this lane's first column inside a fragment pair
+#pragma unroll
+  for (int q = 0; q < R::NP; ++q) *(uint4*)(row + 32 * q + pc) = r.pr[q];
+#pragma unroll
+  for (int t = 0; t < R::NT; ++t) {
+    const int d = 16 * (2 * R::NP + t) + 4 * g;
+    if (d < HD) *(uint2*)(row + d) = r.tl[t];
+  }
+}
+
 // stage 64 rows x HD (bf16) from global (row stride ld elements) into LDS with pitch PITCH;
 // columns [HD, HDK) must have been zeroed once.
 template <int HD>
@@ -269,16 +322,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
     const float l_tot = group_sum(l_run[qi]);
     const float inv = 1.f / l_tot;
     bf16* orow = out + ((long)b * L + q0 + 16 * qi + i16) * D + h * HD;
-#pragma unroll
-    for (int f = 0; f < C::NFRAG; ++f) {
-      int d = 16 * f + 4 * g;
-      if (d < HD) {
-        bf16x4 v;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = f2bf(o[qi][f][r] * inv);
-        *(bf16x4*)(orow + d) = v;
-      }
-    }
+    AttnRow<HD> orw;
+    attn_pack_row<HD>(orw, o[qi], inv);
+    attn_store_row<HD>(orow, g, orw);
     if (g == 0) lse[(long)bh * L + q0 + 16 * qi + i16] = m_run[qi] + log2f(l_tot);
   }
 }
@@ -361,16 +407,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
     }
   }
   bf16* drow = dqkv + ((long)b * L + q0 + i16) * ld + h * HD;
-#pragma unroll
-  for (int f = 0; f < C::NFRAG; ++f) {
-    int d = 16 * f + 4 * g;
-    if (d < HD) {
-      bf16x4 v;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = f2bf(dq[f][r]);
-      *(bf16x4*)(drow + d) = v;
-    }
-  }
+  AttnRow<HD> qrw;
+  attn_pack_row<HD>(qrw, dq);
+  attn_store_row<HD>(drow, g, qrw);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -461,20 +500,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
     }
   }
   bf16* drow = dqkv + ((long)b * L + k0 + i16) * ld + h * HD;
-#pragma unroll
-  for (int f = 0; f < C::NFRAG; ++f) {
-    int d = 16 * f + 4 * g;
-    if (d < HD) {
-      bf16x4 a, c;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        a[r] = f2bf(dk[f][r]);
-        c[r] = f2bf(dv[f][r]);
-      }
-      *(bf16x4*)(drow + D + d) = a;
-      *(bf16x4*)(drow + 2 * D + d) = c;
-    }
-  }
+  AttnRow<HD> krw, vrw;
+  attn_pack_row<HD>(krw, dk);
+  attn_pack_row<HD>(vrw, dv);
+  attn_store_row<HD>(drow + D, g, krw);
+  attn_store_row<HD>(drow + 2 * D, g, vrw);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -646,16 +676,9 @@ __global__ __launch_bounds__(512) void attn_fwd_sp_kernel(const bf16* __restrict
     }
     const float inv = 1.f / l_tot;
     bf16* orow = out + ((long)b * L + q) * D + h * HD;
-#pragma unroll
-    for (int f = 0; f < C::NFRAG; ++f) {
-      const int d = 16 * f + 4 * g;
-      if (d < HD) {
-        bf16x4 v;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = f2bf(o[f][r] * inv);
-        *(bf16x4*)(orow + d) = v;
-      }
-    }
+    AttnRow<HD> orw;
+    attn_pack_row<HD>(orw, o, inv);
+    attn_store_row<HD>(orow, g, orw);
     if (g == 0) lse[((long)b * H + h) * L + q] = mx + log2f(l_tot);
   }
 }
@@ -832,19 +855,12 @@ __global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __res
         }
       }
       bf16* drow = dqkv + ((long)b * L + k0 + i16) * ld + h * HD;
-#pragma unroll
-      for (int f = 0; f < C::NFRAG; ++f) {
-        const int d = 16 * f + 4 * g;
-        if (d < HD && !(dbg & 1)) {
-          bf16x4 a, c;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            a[r] = f2bf(dk[f][r]);
-            c[r] = f2bf(dv[f][r]);
-          }
-          *(bf16x4*)(drow + D + d) = a;
-          *(bf16x4*)(drow + 2 * D + d) = c;
-        }
+      AttnRow<HD> krw, vrw;
+      attn_pack_row<HD>(krw, dk);
+      attn_pack_row<HD>(vrw, dv);
+      if (!(dbg & 1)) {
+        attn_store_row<HD>(drow + D, g, krw);
+        attn_store_row<HD>(drow + 2 * D, g, vrw);
       }
     }
 
@@ -887,16 +903,9 @@ __global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __res
         }
       }
       bf16* drow = dqkv + ((long)b * L + q) * ld + h * HD;
-#pragma unroll
-      for (int f = 0; f < C::NFRAG; ++f) {
-        const int d = 16 * f + 4 * g;
-        if (d < HD && !(dbg & 1)) {
-          bf16x4 v;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = f2bf(dq[f][r]);
-          *(bf16x4*)(drow + d) = v;
-        }
-      }
+      AttnRow<HD> qrw;
+      attn_pack_row<HD>(qrw, dq);
+      if (!(dbg & 1)) attn_store_row<HD>(drow, g, qrw);
     }
     if (!has_next) break;  // (OCC != 2: one item per workgroup)
     SP_LDS_BARRIER()       // every wave is done with the tiles before the next item overwrites them
@@ -911,7 +920,7 @@ template <int HD>
 __device__ __forceinline__ void attn_bwd_item_math(const char* Qs, const char* Ks, const char* Vs, const char* dOs,
                                                    const float* lse_s, const float* del_s, bf16* dbase, long ld, int D,
                                                    int wave, int i16, int g, int Lv, float scale, float scale_log2e,
-                                                   bf16x4 (&q_cur)[AttnCfg<HD>::NFRAG], const bf16x4 (&q_prev)[AttnCfg<HD>::NFRAG]) {
+                                                   AttnRow<HD>& q_cur, const AttnRow<HD>& q_prev) {
   // Store-data registers.  gfx9 reads a store's data from the VGPRs when the store reaches the memory pipeline, so hipcc
   // guards every re-use of such a register with a wait for that store -- vmcnt(0) when the store is the youngest
   // operation, which is exactly the case when the register allocator recycles them a few instructions later.  The
@@ -920,7 +929,7 @@ __device__ __forceinline__ void attn_bwd_item_math(const char* Qs, const char* K
   // them are ten or more operations old and the guard is a cheap counted wait.
   using C = SpCfg<HD>;
   constexpr int L = 128;
-  bf16x4 kv_keep[2 * C::NFRAG];
+  AttnRow<HD> k_keep, v_keep;
   {
     const int k0 = wave * 16;
     bf16x8 kf[C::KSTEPS], vf[C::KSTEPS];
@@ -968,21 +977,11 @@ __device__ __forceinline__ void attn_bwd_item_math(const char* Qs, const char* K
       }
     }
     bf16* drow = dbase + (long)(k0 + i16) * ld;
-#pragma unroll
-    for (int f = 0; f < C::NFRAG; ++f) {
-      const int d = 16 * f + 4 * g;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        kv_keep[2 * f][r] = f2bf(dk[f][r]);
-        kv_keep[2 * f + 1][r] = f2bf(dv[f][r]);
-      }
-      if (d < HD) {
-        *(bf16x4*)(drow + D + d) = kv_keep[2 * f];
-        *(bf16x4*)(drow + 2 * D + d) = kv_keep[2 * f + 1];
-      }
-    }
-#pragma unroll
-    for (int f = 0; f < C::NFRAG; ++f) asm volatile("" ::"v"(q_prev[f]));  // last use of the previous item's dQ data
+    attn_pack_row<HD>(k_keep, dk);
+    attn_pack_row<HD>(v_keep, dv);
+    attn_store_row<HD>(drow + D, g, k_keep);
+    attn_store_row<HD>(drow + 2 * D, g, v_keep);
+    attn_keep_alive<HD>(q_prev);  // last use of the previous item's dQ store data
   }
   {
     const int q = wave * 16 + i16;
@@ -1021,15 +1020,10 @@ __device__ __forceinline__ void attn_bwd_item_math(const char* Qs, const char* K
       }
     }
     bf16* drow = dbase + (long)q * ld;
-#pragma unroll
-    for (int f = 0; f < C::NFRAG; ++f) {
-      const int d = 16 * f + 4 * g;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) q_cur[f][r] = f2bf(dq[f][r]);
-      if (d < HD) *(bf16x4*)(drow + d) = q_cur[f];
-    }
-#pragma unroll
-    for (int f = 0; f < 2 * C::NFRAG; ++f) asm volatile("" ::"v"(kv_keep[f]));  // last use of the dK / dV data
+    attn_pack_row<HD>(q_cur, dq);
+    attn_store_row<HD>(drow, g, q_cur);
+    attn_keep_alive<HD>(k_keep);  // last use of the dK / dV store data
+    attn_keep_alive<HD>(v_keep);
   }
 }
 
@@ -1042,8 +1036,11 @@ __device__ __forceinline__ void attn_bwd_item_math(const char* Qs, const char* K
 // the attn_dbg knob at B 1024: arithmetic alone 461 us, loads alone 333 us, full kernel 861 us): at 255 VGPRs hipcc
 // recycles store-data registers as prefetch targets and serialises the fetch behind the previous item's stores, and
 // the staging registers -> LDS at the top of every item waits for those stores as well.  Here a wave's vmcnt history
-// per item is [9 DMA + lse + 3 O-fragment loads][16 stores], the wait before the buffer hand-over is the counted
-// vmcnt(16) and the stores stay in flight across items.  The two buffers are separate __shared__ objects and the item
+// per item is [9 DMA + lse + 3 O-fragment loads][NSTORE stores], the wait before the buffer hand-over is the counted
+// vmcnt(NSTORE) and the stores stay in flight across items (NSTORE = the delta store + the dQ / dK / dV row stores: 16 with
+// one 8-byte store per fragment, 10 since round 3's 16-byte pair stores -- the count MUST follow the store helper: with
+// the stale 16 the wait let six of the next item's loads through and tests at 2-3 items per workgroup did not notice;
+// tests/test_engine_gpu.py::test_full_batch_backward_is_linear_in_slices_xl2_bs1024 did).  The two buffers are separate __shared__ objects and the item
 // loop is unrolled by two, so every LDS access names its buffer statically and hipcc does not guard LDS reads of one
 // buffer with a wait for the DMA into the other.
 template <int HD>
@@ -1058,6 +1055,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dma_kernel(const bf16* __rest
   constexpr int HALF_CH = L * C::CH / 2;  // chunks moved by one wave: 576 = 9 instructions of 64 lanes
   static_assert(HALF_CH % 64 == 0, "a wave moves whole 1-KiB pieces");
   constexpr int NDMA = HALF_CH / 64;
+  constexpr int NSTORE = 1 + 3 * (AttnRow<HD>::NP + AttnRow<HD>::NT);
   __shared__ __attribute__((aligned(16))) char buf0[4 * TILE];
   __shared__ __attribute__((aligned(16))) char buf1[4 * TILE];
   __shared__ float lse_s0[L], lse_s1[L], del_s[L];
@@ -1088,9 +1086,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dma_kernel(const bf16* __rest
 
   float lse_r = 0.f;
   bf16x8 of0[C::KSTEPS], of1[C::KSTEPS];  // O fragments of this wave's queries for the item in buffer 0 / 1
-  bf16x4 qk0[C::NFRAG], qk1[C::NFRAG];    // packed dQ store data of the item computed from buffer 0 / 1 (see item_math)
+  AttnRow<HD> qk0, qk1;                   // packed dQ store data of the item computed from buffer 0 / 1 (see item_math)
 #pragma unroll
-  for (int f = 0; f < C::NFRAG; ++f) qk0[f] = qk1[f] = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+  for (int q = 0; q < (AttnRow<HD>::NP > 0 ? AttnRow<HD>::NP : 1); ++q) qk0.pr[q] = qk1.pr[q] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+  for (int t = 0; t < (AttnRow<HD>::NT > 0 ? AttnRow<HD>::NT : 1); ++t) qk0.tl[t] = qk1.tl[t] = make_uint2(0u, 0u);
   const int qrow = wave * 16 + i16;        // this lane's query (phase B, delta) -- and key (phase A) -- row
 
   // workgroup barrier that orders LDS only: __syncthreads() carries a workgroup-scope release fence, for which hipcc
@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dma_kernel(const bf16* __rest
     const char* dOs = CUR + 3 * TILE;                                                                      \
     /* my share of this item has landed (everything younger is a store of the previous item) */            \
     asm volatile("" ::: "memory");                                                                         \
-    __builtin_amdgcn_s_waitcnt((16 & 15) | (7 << 4) | (15 << 8) | ((16 >> 4) << 14)); /* vmcnt(16) */      \
+    __builtin_amdgcn_s_waitcnt((NSTORE & 15) | (7 << 4) | (15 << 8) | ((NSTORE >> 4) << 14)); /* vmcnt(NSTORE) */ \
     asm volatile("" ::: "memory");                                                                         \
     if (tid < L) LSE_CUR[tid] = lse_r;                                                                     \
     ATTN_DMA_BARRIER() /* B1: buffer P complete; every wave is done with the other buffer */               \
@@ -1267,16 +1267,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_q_res_kernel(const bf16* __re
       }
     }
     bf16* drow = dqkv + ((long)b * L + q) * ld + h * HD;
-#pragma unroll
-    for (int f = 0; f < C::NFRAG; ++f) {
-      const int d = 16 * f + 4 * g;
-      if (d < HD) {
-        bf16x4 v;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = f2bf(dq[f][r]);
-        *(bf16x4*)(drow + d) = v;
-      }
-    }
+    AttnRow<HD> qrw;
+    attn_pack_row<HD>(qrw, dq);
+    attn_store_row<HD>(drow, g, qrw);
   }
 }
 
@@ -1372,20 +1365,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv_res_kernel(const bf16* __r
       }
     }
     bf16* drow = dqkv + ((long)b * L + k0 + i16) * ld + h * HD;
-#pragma unroll
-    for (int f = 0; f < C::NFRAG; ++f) {
-      const int d = 16 * f + 4 * g;
-      if (d < HD) {
-        bf16x4 a, c;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          a[r] = f2bf(dk[f][r]);
-          c[r] = f2bf(dv[f][r]);
-        }
-        *(bf16x4*)(drow + D + d) = a;
-        *(bf16x4*)(drow + 2 * D + d) = c;
-      }
-    }
+    AttnRow<HD> krw, vrw;
+    attn_pack_row<HD>(krw, dk);
+    attn_pack_row<HD>(vrw, dv);
+    attn_store_row<HD>(drow + D, g, krw);
+    attn_store_row<HD>(drow + 2 * D, g, vrw);
   }
 }
 

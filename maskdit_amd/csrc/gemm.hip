@@ -291,7 +291,7 @@ extern "C" int mdt_gemm_nt(const mdt_gemm_nt_args* a, mdt_stream_t stream) {
   if (a->epi == MDT_EPI_GATE_RES)
     nt8_ok = nt8_ok && a->rows_per_sample % 64 == 0 && a->ldres % 4 == 0 && a->gate_ld % 4 == 0 &&
              (((uintptr_t)a->res | (uintptr_t)a->gate) & 15) == 0;
-  if (a->epi == MDT_EPI_DGELU || a->epi == MDT_EPI_DSILU) nt8_ok = nt8_ok && a->ldaux % 4 == 0 && ((uintptr_t)a->aux & 7) == 0;
+  if (a->epi == MDT_EPI_DGELU || a->epi == MDT_EPI_DSILU) nt8_ok = nt8_ok && a->ldaux % 8 == 0 && ((uintptr_t)a->aux & 15) == 0;  // 16-byte pair loads
   if (nt8_ok) {
     if (mdt_get_tuning_int(MDT_TUNE_NT8_SKIP_EPILOGUE)) p.epi |= 0x100;
     if (const int stg = mdt_get_tuning_int(MDT_TUNE_NT8_STAGGER)) p.epi |= 0x200 | ((stg < 255 ? stg : 255) << 16);

@@ -118,7 +118,14 @@ __device__ __forceinline__ f32x4 unpack_bf16x4(uint2 u) {
 // (j, j+1) are exchanged between the odd and even 16-lane rows with v_permlane16_swap so that every lane stores
 // 8 consecutive columns (16 bytes): even g -> fragment j columns 4g..4g+7, odd g -> fragment j+1 columns
 // 4(g-1)..4(g-1)+7.
-template <int NF> __device__ __forceinline__ void store_band_bf16(char* ub, unsigned lo_pair, unsigned lo_tail, const f32x4* y) {
+// For an ODD fragment count the last fragment of band i (8 bytes per lane) is not stored on its own: it is carried to
+// band i + 1 and exchanged with that band's last fragment the same way, so that ONE 16-byte store per lane writes both
+// (even 16-lane rows: 8 columns of band i's row, odd rows: 8 columns of band i + 1's row; `lo_tail2` = bf16_tail2_offset
+// relative to the EVEN band).  8-byte accesses run at 0.54-0.70 of the 16-byte rate: 12 instead of 16 store instructions
+// per wave and 256 x 192 tile.
+struct TailCarry { unsigned lo, hi; };
+template <int NF, bool ODD_BAND>
+__device__ __forceinline__ void store_band_bf16(char* ub, char* ub_even, unsigned lo_pair, unsigned lo_tail2, const f32x4* y, TailCarry& tc) {
   unsigned lo[NF], hi[NF];
 #pragma unroll
   for (int j = 0; j < NF; ++j) {
@@ -131,18 +138,63 @@ template <int NF> __device__ __forceinline__ void store_band_bf16(char* ub, unsi
     auto b = __builtin_amdgcn_permlane16_swap(hi[j], hi[j + 1], false, false);
     *(uint4*)(ub + opaque(lo_pair) + 32 * j) = make_uint4(a[0], b[0], a[1], b[1]);
   }
-  if (NF & 1) *(uint2*)(ub + opaque(lo_tail) + 32 * (NF - 1)) = make_uint2(lo[NF - 1], hi[NF - 1]);
+  if (NF & 1) {
+    if (!ODD_BAND) {
+      tc.lo = lo[NF - 1];
+      tc.hi = hi[NF - 1];
+    } else {
+      auto a = __builtin_amdgcn_permlane16_swap(tc.lo, lo[NF - 1], false, false);
+      auto b = __builtin_amdgcn_permlane16_swap(tc.hi, hi[NF - 1], false, false);
+      *(uint4*)(ub_even + opaque(lo_tail2) + 32 * (NF - 1)) = make_uint4(a[0], b[0], a[1], b[1]);
+    }
+  }
 }
+// band i of a [rows, ld] bf16 array at wave-uniform base `base0` (band 0): the constant-index wrapper the epilogues use
+#define NT8_STORE_BAND(NFV, base0, ld, i, lp, lt2, y, tc)                                                     \
+  do {                                                                                                       \
+    if ((i) & 1) store_band_bf16<NFV, true>(band(base0, (i), (ld), 2), band(base0, (i) - 1, (ld), 2), lp, lt2, y, tc); \
+    else store_band_bf16<NFV, false>(band(base0, (i), (ld), 2), band(base0, (i), (ld), 2), lp, lt2, y, tc);   \
+  } while (0)
 // (measured and dropped, round 3: whole-128-byte-line stores for NF = 4 -- the second 64-byte piece of a row rotated by 8
 // lanes with DPP row_ror:8 so that one instruction writes 8 rows x 128 B.  tools/micro/store_bench.hip: a lone CU writes
 // 64-byte segments at <= 24 GB/s and whole lines at >= 51 GB/s, but inside this epilogue nothing moved (1156 vs 1164 us at
 // 256 CUs, 4.5 vs 4.75 us per tile at 128 CUs, with or without a half-period workgroup stagger: gpurun_out/r3/nt8_lines2.log)
 // -- with every CU in its epilogue at once the stores run at the chip's HBM write rate, 5-6 TB/s.)
+// The inverse of store_band_bf16: load one 16-row band of a bf16 array as 16 bytes per lane (8 consecutive columns of a
+// fragment pair; 8 bytes for an odd last fragment) and hand every lane the 4 columns per fragment the accumulators use
+// (v_permlane16_swap is its own inverse on a pair).  Half as many load instructions as one 8-byte load per fragment --
+// 8-byte accesses run at 0.54-0.70 of the 16-byte rate (MI355X_MICROARCH.md).  raw[] is kept in the packed form so that
+// the look-ahead costs the same registers as before.
+template <int NF> struct BandRaw {
+  uint4 pr[NF / 2 > 0 ? NF / 2 : 1];
+  uint2 tail;
+};
+template <int NF> __device__ __forceinline__ void load_band_bf16(BandRaw<NF>& r, const char* ub, unsigned lo_pair, unsigned lo_tail) {
+#pragma unroll
+  for (int j = 0; j + 1 < NF; j += 2) r.pr[j / 2] = *(const uint4*)(ub + opaque(lo_pair) + 32 * j);
+  if (NF & 1) r.tail = *(const uint2*)(ub + opaque(lo_tail) + 32 * (NF - 1));
+}
+template <int NF> __device__ __forceinline__ void unpack_band_bf16(const BandRaw<NF>& r, f32x4* h) {
+#pragma unroll
+  for (int j = 0; j + 1 < NF; j += 2) {
+    const uint4 x = r.pr[j / 2];  // (a0, b0, a1, b1) of store_band_bf16
+    auto l = __builtin_amdgcn_permlane16_swap(x.x, x.z, false, false);
+    auto hh = __builtin_amdgcn_permlane16_swap(x.y, x.w, false, false);
+    h[j] = unpack_bf16x4(make_uint2(l[0], hh[0]));
+    h[j + 1] = unpack_bf16x4(make_uint2(l[1], hh[1]));
+  }
+  if (NF & 1) h[NF - 1] = unpack_bf16x4(r.tail);
+}
+
 // lane byte offsets into a bf16 [rows, ld] array for store_band_bf16 (fr = lane & 15, fg = lane >> 4)
 __device__ __forceinline__ unsigned bf16_pair_offset(int fr, int fg, int ld) {
   return (unsigned)(fr * ld + ((fg & 1) ? 16 + 4 * (fg - 1) : 4 * fg)) * 2u;
 }
 __device__ __forceinline__ unsigned bf16_tail_offset(int fr, int fg, int ld) { return (unsigned)(fr * ld + 4 * fg) * 2u; }
+// paired tail store (store_band_bf16): even 16-lane rows write band i's row fr, odd rows band i + 1's row fr (+ 16 rows)
+__device__ __forceinline__ unsigned bf16_tail2_offset(int fr, int fg, int ld) {
+  return (unsigned)((fr + ((fg & 1) ? 16 : 0)) * ld + ((fg & 1) ? 4 * (fg - 1) : 4 * fg)) * 2u;
+}
 
 // look-ahead (in 16-row bands) of the epilogue's row-dependent loads: as deep as the register file allows
 constexpr int epi_depth(int E, int NF) {
@@ -507,13 +559,14 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
 #pragma unroll
       for (int j = 0; j < NF; ++j) csum[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       char* ob = ubase(p.out, p.ldo, 2);
-      const unsigned lp = bf16_pair_offset(fr, fg, p.ldo), lt = bf16_tail_offset(fr, fg, p.ldo);
+      const unsigned lp = bf16_pair_offset(fr, fg, p.ldo), lt2 = bf16_tail2_offset(fr, fg, p.ldo);
+      TailCarry tc = {0u, 0u};
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         f32x4 y[NF];
 #pragma unroll
         for (int j = 0; j < NF; ++j) y[j] = acc[i][j] + bias[j];
-        store_band_bf16<NF>(band(ob, i, p.ldo, 2), lp, lt, y);
+        NT8_STORE_BAND(NF, ob, p.ldo, i, lp, lt2, y, tc);
         if (CS) {
 #pragma unroll
           for (int j = 0; j < NF; ++j) csum[j] += round_bf16(y[j]);
@@ -535,8 +588,9 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
       constexpr bool KH = decltype(keep_h)::value, GELU = decltype(is_gelu)::value;
       char* hb = KH ? ubase(p.out, p.ldo, 2) : nullptr;
       char* ab = ubase(p.out2, p.ldo2, 2);
-      const unsigned hp = bf16_pair_offset(fr, fg, p.ldo), ht = bf16_tail_offset(fr, fg, p.ldo);
-      const unsigned ap = bf16_pair_offset(fr, fg, p.ldo2), at = bf16_tail_offset(fr, fg, p.ldo2);
+      const unsigned hp = bf16_pair_offset(fr, fg, p.ldo), ht2 = bf16_tail2_offset(fr, fg, p.ldo);
+      const unsigned ap = bf16_pair_offset(fr, fg, p.ldo2), at2 = bf16_tail2_offset(fr, fg, p.ldo2);
+      TailCarry tch = {0u, 0u}, tca = {0u, 0u};
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         f32x4 y[NF], a[NF];
@@ -546,8 +600,8 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
 #pragma unroll
           for (int c = 0; c < 4; ++c) a[j][c] = GELU ? gelu_tanh(y[j][c]) : silu(y[j][c]);
         }
-        if (KH) store_band_bf16<NF>(band(hb, i, p.ldo, 2), hp, ht, y);
-        store_band_bf16<NF>(band(ab, i, p.ldo2, 2), ap, at, a);
+        if (KH) NT8_STORE_BAND(NF, hb, p.ldo, i, hp, ht2, y, tch);
+        NT8_STORE_BAND(NF, ab, p.ldo2, i, ap, at2, a, tca);
       }
     };
     if (act == MDT_EPI_GELU) { if (p.out) body(T{}, T{}); else body(F{}, T{}); }
@@ -562,7 +616,8 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
       char* fb = ubase(p.outf, p.ldof, 4);
       char* yb = KY ? ubase(p.out, p.ldo, 2) : nullptr;
       const unsigned lr_ = (unsigned)(fr * p.ldres + 4 * fg) * 4u, lf = (unsigned)(fr * p.ldof + 4 * fg) * 4u;
-      const unsigned yp = bf16_pair_offset(fr, fg, p.ldo), yt = bf16_tail_offset(fr, fg, p.ldo);
+      const unsigned yp = bf16_pair_offset(fr, fg, p.ldo), yt2 = bf16_tail2_offset(fr, fg, p.ldo);
+      TailCarry tcy = {0u, 0u};
       const char* g0 = (const char*)(p.gate + (long)(em0 / p.rows_per_sample) * p.gate_ld + en0);
       const char* g1 = (const char*)(p.gate + (long)((em0 + 64) / p.rows_per_sample) * p.gate_ld + en0);
       const unsigned lg = 16u * fg;
@@ -588,7 +643,7 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
         }
 #pragma unroll
         for (int j = 0; j < NF; ++j) *(f32x4*)(band(fb, i, p.ldof, 4) + opaque(lf) + 64 * j) = pre[i][j] + gate[G2 ? (i >> 2) : 0][j] * y[j];
-        if (KY) store_band_bf16<NF>(band(yb, i, p.ldo, 2), yp, yt, y);
+        if (KY) NT8_STORE_BAND(NF, yb, p.ldo, i, yp, yt2, y, tcy);
       }
     };
     // rows_per_sample % 128 == 0 (every shipped shape): the wave's 128-row block lies in ONE sample
@@ -600,13 +655,12 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
       constexpr int D = epi_depth(E, NF);
       char* xb = ubase(p.aux, p.ldaux, 2);
       char* ob = ubase(p.out, p.ldo, 2);
-      const unsigned lx = bf16_tail_offset(fr, fg, p.ldaux);
-      const unsigned lp = bf16_pair_offset(fr, fg, p.ldo), lt = bf16_tail_offset(fr, fg, p.ldo);
-      uint2 pre[8][NF];
+      const unsigned lxp = bf16_pair_offset(fr, fg, p.ldaux), lxt = bf16_tail_offset(fr, fg, p.ldaux);
+      const unsigned lp = bf16_pair_offset(fr, fg, p.ldo), lt2 = bf16_tail2_offset(fr, fg, p.ldo);
+      TailCarry tc = {0u, 0u};
+      BandRaw<NF> pre[8];  // saved pre-activation, 16 bytes per lane and fragment pair (round 2: one 8-byte load per fragment)
 #pragma unroll
-      for (int i = 0; i < (D < 8 ? D : 8); ++i)
-#pragma unroll
-        for (int j = 0; j < NF; ++j) pre[i][j] = *(const uint2*)(band(xb, i, p.ldaux, 2) + opaque(lx) + 32 * j);
+      for (int i = 0; i < (D < 8 ? D : 8); ++i) load_band_bf16<NF>(pre[i], band(xb, i, p.ldaux, 2), lxp, lxt);
       __builtin_amdgcn_sched_barrier(0);
       f32x4 csum[NF];
 #pragma unroll
@@ -615,17 +669,27 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
       for (int i = 0; i < 8; ++i) {
         f32x4 y[NF];
 #pragma unroll
-        for (int j = 0; j < NF; ++j) {
-          const f32x4 h = unpack_bf16x4(pre[i][j]);
-          const f32x4 v = acc[i][j] + bias[j];
+        for (int j0 = 0; j0 < NF; j0 += 2) {  // one fragment pair at a time: short live ranges for the unpacked values
+          f32x4 hb[2];
+          if (j0 + 1 < NF) {
+            const uint4 x = pre[i].pr[j0 / 2];
+            auto l = __builtin_amdgcn_permlane16_swap(x.x, x.z, false, false);
+            auto hh = __builtin_amdgcn_permlane16_swap(x.y, x.w, false, false);
+            hb[0] = unpack_bf16x4(make_uint2(l[0], hh[0]));
+            hb[1] = unpack_bf16x4(make_uint2(l[1], hh[1]));
+          } else {
+            hb[0] = unpack_bf16x4(pre[i].tail);
+          }
 #pragma unroll
-          for (int c = 0; c < 4; ++c) y[j][c] = v[c] * (GELU ? gelu_tanh_grad(h[c]) : silu_grad(h[c]));
-        }
-        if (i + D < 8) {
+          for (int jj = 0; jj < 2 && j0 + jj < NF; ++jj) {
+            const int j = j0 + jj;
+            const f32x4 v = acc[i][j] + bias[j];
 #pragma unroll
-          for (int j = 0; j < NF; ++j) pre[i + D][j] = *(const uint2*)(band(xb, i + D, p.ldaux, 2) + opaque(lx) + 32 * j);
+            for (int c = 0; c < 4; ++c) y[j][c] = v[c] * (GELU ? gelu_tanh_grad(hb[jj][c]) : silu_grad(hb[jj][c]));
+          }
         }
-        store_band_bf16<NF>(band(ob, i, p.ldo, 2), lp, lt, y);
+        if (i + D < 8) load_band_bf16<NF>(pre[i + D], band(xb, i + D, p.ldaux, 2), lxp, lxt);
+        NT8_STORE_BAND(NF, ob, p.ldo, i, lp, lt2, y, tc);
         if (CS) {
 #pragma unroll
           for (int j = 0; j < NF; ++j) csum[j] += round_bf16(y[j]);
