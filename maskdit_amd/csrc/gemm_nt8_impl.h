@@ -254,7 +254,10 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
   const int ntiles = tiles_m * tiles_n;
   int vt = blockIdx.x;  // virtual tile id of this workgroup's current tile (stride gridDim.x)
   int tm, tn;
-  const int group_m = p.group_m > 0 ? p.group_m : GROUP_M;
+  // tile order: groups of 8 row tiles, 4 where the problem has few column tiles (N = 1152: 6) -- the 32 concurrent
+  // workgroups of an XCD then share fewer distinct A rows (fc1 dgrad 1077 -> 1019 us, proj dgrad 310 -> 301; wide
+  // problems prefer 8: gpurun_out/r3/nt8_group.log)
+  const int group_m = p.group_m > 0 ? p.group_m : (tiles_n <= 8 ? 4 : GROUP_M);
   tile_coords(xcd_remap(vt, ntiles), tiles_m, tiles_n, tm, tn, group_m);
   int m0 = tm * BM8, n0 = tn * BN8;
 

@@ -48,6 +48,7 @@ struct TN8Params {
   int slots_per_split;
   int tiles_x, tiles_y;
   float* colsum_x;     // optional [NX]: += column sums of X over this launch's rows (see the kernel)
+  int group_x;         // X tiles per group of the tile order (the 32 concurrent workgroups of an XCD cover group_x x 32/group_x tiles)
   int dbg;             // timing experiments only (knob tn8_dbg): 1 = no slot refills, 2 = no fragment reads, 4 = refills re-read the first slots
 };
 
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TN8Params p) {
   const int sid = xcd_remap(blockIdx.x, gridDim.x);
   const int split = sid / tiles;
   int tx, ty;
-  tile_coords(sid - split * tiles, p.tiles_x, p.tiles_y, tx, ty);
+  tile_coords(sid - split * tiles, p.tiles_x, p.tiles_y, tx, ty, p.group_x);
   const int x0 = tx * 256, y0 = ty * Cfg::TY;
   const int s_begin = split * p.slots_per_split;
   const int S = min(p.slots_per_split, p.slots_total - s_begin);  // >= NSLOT (host guarantees)
@@ -401,6 +402,10 @@ int launch_gemm_tn8(const bf16* A, int lda, const bf16* B, int ldb, int M, int N
   p.colsum_x = (colsum_a && a_is_x && p.tiles_y >= 2) ? colsum_a : nullptr;
   if (colsum_done) *colsum_done = p.colsum_x != nullptr;
   p.dbg = mdt_get_tuning_int(MDT_TUNE_TN8_DBG);
+  // tile order: groups of 2 X tiles, Y fastest -- the 32 concurrent workgroups of an XCD then cover ~5 X tiles x all 6 Y
+  // tiles = 2517 distinct operand columns per streamed row instead of 2816 with groups of 8 (fc1 / fc2 weight gradients
+  // -3..-7 %, gpurun_out/r3/tn8_group.log); tn8_dbg bits 4-7 override it for A/B runs
+  p.group_x = ((p.dbg >> 4) & 15) ? ((p.dbg >> 4) & 15) : 2;
   const int nslot = yf == 6 ? TN8Cfg<6>::NSLOT : TN8Cfg<4>::NSLOT;
   p.slots_total = M / 32;
   const int tiles = p.tiles_x * p.tiles_y;
