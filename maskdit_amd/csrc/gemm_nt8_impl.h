@@ -257,7 +257,10 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
   // tile order: groups of 8 row tiles, 4 where the problem has few column tiles (N = 1152: 6) -- the 32 concurrent
   // workgroups of an XCD then share fewer distinct A rows (fc1 dgrad 1077 -> 1019 us, proj dgrad 310 -> 301; wide
   // problems prefer 8: gpurun_out/r3/nt8_group.log)
-  const int group_m = p.group_m > 0 ? p.group_m : (tiles_n <= 8 ? 4 : GROUP_M);
+  // ... and 3 where N is a power of two (the 512- / 2048-wide decoder): with power-of-two row pitches the row tiles an
+  // XCD works on at the same time sit at multiples of 512 KB - 2 MB, i.e. on the same HBM channels; an odd group spreads
+  // them (decoder proj + GATE_RES 400 -> 337 us, fc1 + GELU 801 -> 740: gpurun_out/r3/nt8_groups_all.log)
+  const int group_m = p.group_m > 0 ? p.group_m : ((p.N & (p.N - 1)) == 0 ? 3 : tiles_n <= 8 ? 4 : GROUP_M);
   tile_coords(xcd_remap(vt, ntiles), tiles_m, tiles_n, tm, tn, group_m);
   int m0 = tm * BM8, n0 = tn * BN8;
 

@@ -26,6 +26,7 @@ def main():
     ap.add_argument('--iters', type=int, default=5)
     ap.add_argument('--rounds', type=int, default=2)
     ap.add_argument('--decoder', action='store_true')
+    ap.add_argument('--groups', action='store_true', help='sweep the tile-order group (nt8_group_m) instead of the kernel forms')
     args = ap.parse_args()
     L = _lib.lib()
     dev = 'cuda'
@@ -45,7 +46,9 @@ def main():
                    ((Md, 512, 2048), 'GATE_RES', 'dec fc2'), ((Md, 2048, 512), 'DGELU', 'dec fc2 dgrad'), ((Md, 512, 2048), 'BF16', 'dec fc1 dgrad')]
     variants = [('full', {}), ('no-epi', {'nt8_skip_epilogue': 1}), ('nf3', {'nt8_nf3': 1}), ('4-wave', {'gemm_nt_variant': 3}),
                 ('240 CUs', {'nt8_max_cus': 240}), ('trickle', {'nt8_trickle': 1})]
-    knobs = ['nt8_skip_epilogue', 'nt8_nf3', 'nt8_stagger', 'gemm_nt_variant', 'nt8_max_cus', 'nt8_trickle']
+    knobs = ['nt8_skip_epilogue', 'nt8_nf3', 'nt8_stagger', 'gemm_nt_variant', 'nt8_max_cus', 'nt8_trickle', 'nt8_group_m']
+    if args.groups:
+        variants = [('auto', {})] + [(f'g{g}', {'nt8_group_m': g}) for g in (1, 2, 3, 4, 6, 8, 12, 16)]
     print(f'{"shape / epilogue":40s} ' + ' '.join(f'{v[0]:>16s}' for v in variants) + '    (TFLOP/s | us)')
     for (m, n, k), name, tag in shapes:
         A = (torch.randn(m, k, device=dev) * 0.5).to(torch.bfloat16)
