@@ -241,8 +241,9 @@ int mdt_cfg_combine(const float* F, float cfg_scale, float* out, long n, mdt_str
 /* ---------------------------------------------------------------- VAE decoder glue ------ */
 
 /* The KL-autoencoder decoder that follows the sampler (autoencoder.py:306-410 Decoder, :449-453 decode; call sites
- * sample.py:248,273-284).  Activations are NHWC fp32 [B*H*W, C]; every convolution is one mdt_gemm_nt on an im2col
- * matrix written by mdt_gn_im2col with the GroupNorm / swish / up-sampling in front of it already applied. */
+ * sample.py:248,273-284).  Activations are NHWC fp32 [B*H*W, C]; mdt_gn_im2col applies the GroupNorm / swish in front of a
+ * convolution and writes bf16: the normalised activation itself (ksize 1) for mdt_conv3x3_nhwc / the 1x1 convolutions, or an
+ * im2col matrix for mdt_gemm_nt where the channel count is not a multiple of 64 (conv_in). */
 /* sums[b, g, 0..1] = (sum, sum of squares) over the H*W*(C/groups) elements of group g (autoencoder.py:35-36
  * Normalize = GroupNorm(32, eps 1e-6, affine)); cleared on the stream by the call. */
 int mdt_gn_stats(const float* x, float* sums, int B, int HW, int C, int groups, mdt_stream_t stream);
@@ -252,6 +253,15 @@ int mdt_gn_stats(const float* x, float* sums, int B, int HW, int C, int groups, 
  * no normalisation (conv_in, the up-sampling convolutions, nin_shortcut). */
 int mdt_gn_im2col(const float* x, const float* sums, const float* gamma, const float* beta, mdt_bf16* col, int B, int H,
                   int W, int C, int groups, int ksize, int upsample, int swish, int Kp, mdt_stream_t stream);
+/* out[(b, y, x), n] = bias[n] + sum_{ky, kx, c} act[b, (y + ky - 1) >> up, (x + kx - 1) >> up, c] * W[n, (ky * 3 + kx) * C + c]
+ * (zero outside the Ho x Ho image, Ho = Hi << up): nn.Conv2d(C, Cout, 3, padding = 1) of ResnetBlock.conv1/2, conv_out and
+ * Upsample.conv behind interpolate(nearest, 2x) (autoencoder.py:35-52, 78-140, 306-410) as an IMPLICIT GEMM -- the bf16
+ * MFMA kernel of mdt_gemm_nt gathers its A operand straight from the NHWC activation; no im2col matrix.  `act`: bf16
+ * [B, Hi, Hi, C] (what mdt_gn_im2col writes with ksize 1: GroupNorm + swish applied), C % 128 == 0, Hi a power of two,
+ * and THE 256 BYTES IN FRONT OF `act` MUST BE ZERO (the padding taps read them).  W: bf16 [Np, 9 C], Np % 128 == 0;
+ * out: fp32 [B * Ho * Ho, ldo]. */
+int mdt_conv3x3_nhwc(const mdt_bf16* act, int B, int Hi, int C, int up, const mdt_bf16* W, const float* bias, float* out,
+                     int ldo, int Np, mdt_stream_t stream);
 /* out[r, :] = softmax(in[r, :] * scale) as bf16 (AttnBlock, autoencoder.py:188-190) */
 int mdt_softmax_rows(const float* in, mdt_bf16* out, int R, int n, float scale, mdt_stream_t stream);
 /* y[b, p, :] = W (z[b, :, p] / scale_factor) + bias: FrozenAutoencoderKL.decode's rescale + post_quant_conv

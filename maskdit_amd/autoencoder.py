@@ -8,9 +8,11 @@ Parameters carry the reference's state-dict names and shapes (`decoder.mid.block
 so the published `autoencoder_kl.pth` loads with `load_state_dict` (its `encoder.*` / `quant_conv.*` entries are
 accepted and ignored: encoding is outside the sampling path -- training consumes pre-computed latents).
 
-Arithmetic (maskdit_amd/csrc/vae.hip + the bf16 MFMA GEMMs): activations NHWC fp32; every 3x3 / 1x1 convolution is ONE
-`mdt_gemm_nt` (bf16 operands, fp32 accumulate, fp32 output + bias) on an im2col matrix that `mdt_gn_im2col` writes with
-GroupNorm(32, eps 1e-6) + swish + nearest 2x up-sampling + zero padding already applied; the mid-block attention
+Arithmetic (maskdit_amd/csrc/vae.hip + the bf16 MFMA GEMMs): activations NHWC fp32; `mdt_gn_im2col` applies GroupNorm(32,
+eps 1e-6) + swish and writes the bf16 operand; every 3x3 convolution with a multiple of 128 input channels is ONE implicit
+GEMM (`mdt_conv3x3_nhwc`, round 3: the MFMA kernel gathers the nine taps, the zero padding and the nearest 2x up-sampling
+from the NHWC activation -- rounds 1-2 materialised an im2col matrix of 9x the activation bytes), the 1x1 convolutions and
+conv_in (4 channels) are `mdt_gemm_nt` on the activation / a small im2col matrix; the mid-block attention
 (1024 tokens, one head of 512 channels) is three GEMMs per image around `mdt_softmax_rows`.  No torch arithmetic, no
 CPU fallback.  ddconfig is the reference's (ch 128, ch_mult (1, 2, 4, 4), 2 res blocks, no attention resolutions,
 z_channels 4, 3 output channels)."""
@@ -89,6 +91,7 @@ class FrozenAutoencoderKL(nn.Module):
             self.register_parameter(name.replace('.', '__'), p)  # flat registration, reference names restored below
             self._names.append(name)
         self._packed: Optional[dict] = None
+        self._wdict: Optional[dict] = None
         self._ws: Dict[tuple, torch.Tensor] = {}
         if pretrained_path is not None:
             sd = torch.load(pretrained_path, map_location='cpu')
@@ -122,6 +125,8 @@ class FrozenAutoencoderKL(nn.Module):
 
     def _apply(self, fn, *a, **k):
         self._packed = None
+        self._wdict = None
+        self._act_zeroed = None
         self._ws.clear()
         return super()._apply(fn, *a, **k)
 
@@ -151,6 +156,12 @@ class FrozenAutoencoderKL(nn.Module):
         self._packed = pk
         return pk
 
+    def _weights(self):
+        """name -> parameter, built once per device binding (round 2 rebuilt this dict for every convolution)"""
+        if self._wdict is None:
+            self._wdict = dict(self.named_weights())
+        return self._wdict
+
     def _buf(self, key, shape, dtype):
         t = self._ws.get(key)
         n = 1
@@ -165,7 +176,7 @@ class FrozenAutoencoderKL(nn.Module):
     def _conv(self, x, B, H, cin, name, k=3, norm=None, swish=False, up=0, slot='a'):
         """x: fp32 [B*H*H, cin] (NHWC) -> fp32 [B*Ho*Ho, Np]"""
         st = ops.stream_ptr()
-        W = dict(self.named_weights())
+        W = self._weights()
         wmat, bias, Kp, Np = self._packed[name]
         sums = gamma = beta = None
         if norm is not None:
@@ -174,6 +185,21 @@ class FrozenAutoencoderKL(nn.Module):
             gamma, beta = W[norm + '.weight'], W[norm + '.bias']
         Ho = H << up
         M = B * Ho * Ho
+        if k == 3 and cin % 128 == 0:
+            # implicit GEMM (round 3): the normalised activation is written ONCE as bf16 NHWC (ksize-1 form of
+            # mdt_gn_im2col) behind a 256-byte zero line, the MFMA kernel gathers the nine taps (and the 2x up-sampling)
+            # itself -- no im2col matrix (9x the activation bytes per convolution in rounds 1-2)
+            raw = self._buf('act', (128 + B * H * H * cin,), torch.bfloat16)
+            if getattr(self, '_act_zeroed', None) != raw.data_ptr():
+                raw[:128].zero_()
+                self._act_zeroed = raw.data_ptr()
+            act = raw[128:]
+            call('mdt_gn_im2col', x.data_ptr(), sums.data_ptr() if sums is not None else None,
+                 gamma.data_ptr() if gamma is not None else None, beta.data_ptr() if beta is not None else None, act.data_ptr(),
+                 B, H, H, cin, GROUPS, 1, 0, int(swish), cin, st)
+            out = self._buf('out_' + slot, (M, Np), torch.float32)
+            call('mdt_conv3x3_nhwc', act.data_ptr(), B, H, cin, up, wmat.data_ptr(), bias.data_ptr(), out.data_ptr(), Np, Np, st)
+            return out
         col = self._buf('col', (M, Kp), torch.bfloat16)
         call('mdt_gn_im2col', x.data_ptr(), sums.data_ptr() if sums is not None else None,
              gamma.data_ptr() if gamma is not None else None, beta.data_ptr() if beta is not None else None, col.data_ptr(),
@@ -196,7 +222,7 @@ class FrozenAutoencoderKL(nn.Module):
 
     def _attn(self, x, B, H, c, name, slot):
         st = ops.stream_ptr()
-        W = dict(self.named_weights())
+        W = self._weights()
         T = H * H
         sums = self._buf('sums', (B, GROUPS, 2), torch.float32)
         call('mdt_gn_stats', x.data_ptr(), sums.data_ptr(), B, T, c, GROUPS, st)
@@ -237,7 +263,7 @@ class FrozenAutoencoderKL(nn.Module):
         B, C, R, R2 = z.shape
         assert C == Z_CH and R == R2 and R % 8 == 0, f'latent shape {tuple(z.shape)}'
         st = ops.stream_ptr()
-        W = dict(self.named_weights())
+        W = self._weights()
         x = self._buf('x0', (B * R * R, Z_CH), torch.float32)
         call('mdt_vae_prologue', z.data_ptr(), W['post_quant_conv.weight'].data_ptr(), W['post_quant_conv.bias'].data_ptr(),
              x.data_ptr(), B, R * R, float(self.scale_factor), st)
@@ -273,6 +299,7 @@ class FrozenAutoencoderKL(nn.Module):
 
     def release_workspace(self):
         self._ws.clear()
+        self._act_zeroed = None
 
 
 def get_model(pretrained_path: Optional[str], scale_factor: float = 0.18215) -> FrozenAutoencoderKL:

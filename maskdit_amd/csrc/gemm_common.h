@@ -21,6 +21,10 @@ struct NTParams {
   int k_splits;
   int group_m;  // tile-order group height (0 = GROUP_M)
   float* colsum;  // optional: colsum[n] += sum over rows of the bf16-rounded `out` (bias gradient of the producer)
+  // implicit 3x3 convolution (gemm_nt8 CONV instantiations only; mdt_conv3x3_nhwc): A is not a matrix but an NHWC bf16
+  // activation [B, Hi, Hi, C] whose 256 bytes in front are zero; row m = output pixel (b, y, x) of an Ho x Ho image
+  // (Ho = Hi << conv_up, nearest-neighbour up-sampling folded into the gather), K index = (tap, channel)
+  int conv_ho_log2, conv_up, conv_c;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

@@ -222,6 +222,7 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
   constexpr int QA = SP == 8 ? QLAST : SP == 9 ? (9 < QLAST ? 9 : QLAST) : 4;
   constexpr int QB = SP == 8 ? QLAST : SP == 9 ? QLAST : (8 < QLAST ? 8 : QLAST);
   constexpr bool FJ = NF == 4 && (SP == 5 || SP == 11);
+  constexpr bool CONV = (SCHED & 4096) != 0;  // A operand gathered from an NHWC activation (implicit 3x3 convolution)
   constexpr bool XPF = !(SCHED & 1024) && E != E_TRK;  // cross-tile prefetch inside the last K-tile pair (bit 10 = the round-2 burst, A/B runs)
   // (measured and dropped: non-temporal epilogue stores -- the plain-bf16 epilogue gets 8-17 % SLOWER, gpurun_out/r3/sched4.log)
   constexpr bool X_NODMA = (SCHED & 32) != 0, X_NOREAD = (SCHED & 64) != 0, X_NOBAR = (SCHED & 128) != 0;
@@ -279,6 +280,19 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
   unsigned a_lo[4], b_lo[NF * RPP];
 #pragma unroll
   for (int q = 0; q < 4; ++q) a_lo[q] = (unsigned)((lr + 32 * q) * p.lda + gch * 8) * 2u;
+  // CONV: a_lo[q] instead holds the output pixel of this lane's row of slot q, packed x | y << 12 | b << 24 (re-derived
+  // per tile); the source offset of a K-tile = the tap-shifted (and, with up-sampling, halved) pixel x C channels, or
+  // the zero line in front of the activation for taps that fall outside the image
+  auto conv_rows = [&](int m_first) {
+    const int hl = p.conv_ho_log2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = m_first + a_row0 + 32 * q + lr;
+      const int pix = m & ((1 << (2 * hl)) - 1);
+      a_lo[q] = (unsigned)((pix & ((1 << hl) - 1)) | ((pix >> hl) << 12) | ((m >> (2 * hl)) << 24));
+    }
+  };
+  if constexpr (CONV) conv_rows(m0);
 #pragma unroll
   for (int j = 0; j < NF * RPP; ++j) b_lo[j] = (unsigned)((lr + BROWS * j) * p.ldb + gch * 8) * 2u;
   const int a_lds0 = a_row0 * 128;           // + 32q*128 + stage*STAGE
@@ -293,7 +307,20 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
     const char* ak = a_u + (long)kt * 128;
     const char* bk = b_u + (long)kt * 128;
     if (SADDR) { ak = sopaque(ak); bk = sopaque(bk); }
-    if (part & 1) glds16(ak + opaque(a_lo[ph]), base + a_lds0 + ph * 4096);
+    if constexpr (CONV) {
+      if (part & 1) {
+        const int kk = kt * 64;                       // K index of this K-tile: tap * C + channel (C % 64 == 0)
+        const int tap = kk / p.conv_c, c0 = kk - tap * p.conv_c;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int hl = p.conv_ho_log2, ho = 1 << hl, hi_l = hl - p.conv_up;
+        const unsigned pk = opaque(a_lo[ph]);
+        const int xx = (int)(pk & 0xfff) + dx, yy = (int)((pk >> 12) & 0xfff) + dy, bb = (int)(pk >> 24);
+        const bool ok = (unsigned)xx < (unsigned)ho && (unsigned)yy < (unsigned)ho;
+        const unsigned pix = (unsigned)((((bb << hi_l) + (yy >> p.conv_up)) << hi_l) + (xx >> p.conv_up));
+        const unsigned off = ok ? 256u + (pix * (unsigned)p.conv_c + (unsigned)c0 + (unsigned)gch * 8u) * 2u : (unsigned)(lane & 7) * 16u;
+        glds16((const char*)p.A + off, base + a_lds0 + ph * 4096);
+      }
+    } else if (part & 1) glds16(ak + opaque(a_lo[ph]), base + a_lds0 + ph * 4096);
     if ((part & 2) && ph < NF) {
 #pragma unroll
       for (int r = 0; r < RPP; ++r) {
@@ -493,6 +520,7 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
     n0 = tn * BN8;
     a_u = (const char*)(p.A + (long)(m0 + a_row0) * p.lda);
     b_u = (const char*)(p.B + (long)(n0 + 8 * wave) * p.ldb);
+    if constexpr (CONV) conv_rows(m0);
   }
   // (a workgroup's LAST tile re-fetches its own first two K-tiles into the freed slots instead of branching to a
   // draining variant: the steady-state waits stay valid, nothing reads those slots again, and a second copy of the

@@ -104,3 +104,37 @@ def test_vae_decode_vs_reference_fixture(golden_dir):
     # 64x64 latents (ImageNet-512): runs, finite, right shape
     big = vae.decode(torch.randn(1, 4, 64, 64, device=DEV) * 0.5)
     assert big.shape == (1, 3, 512, 512) and bool(torch.isfinite(big).all())
+
+
+@pytest.mark.parametrize('B,Hi,C,Cout,up', [(2, 16, 128, 128, 0), (1, 32, 256, 128, 1), (4, 8, 512, 512, 0), (2, 16, 128, 3, 1)])
+def test_conv3x3_implicit_gemm_vs_conv2d(B, Hi, C, Cout, up):
+    """mdt_conv3x3_nhwc (the MFMA kernel gathers the nine taps, the zero padding and the nearest 2x up-sampling from the
+    NHWC bf16 activation) against F.conv2d(padding=1) of the same bf16-rounded operands (autoencoder.py:35-52 Upsample,
+    :78-140 ResnetBlock convolutions); asymmetric random weights detect tap / channel permutations."""
+    import torch.nn.functional as F
+    from maskdit_amd._lib import call
+    from maskdit_amd import ops
+    torch.manual_seed(31)
+    dev = 'cuda'
+    x = torch.randn(B, C, Hi, Hi, device=dev)
+    w = torch.randn(Cout, C, 3, 3, device=dev) / (3.0 * C ** 0.5)
+    bias = torch.randn(Cout, device=dev)
+    xb, wb = x.to(torch.bfloat16), w.to(torch.bfloat16)
+    src = F.interpolate(xb.float(), scale_factor=2, mode='nearest') if up else xb.float()
+    ref = F.conv2d(src, wb.float(), bias, padding=1)                                  # [B, Cout, Ho, Ho]
+    Ho = Hi << up
+    Np = (Cout + 127) // 128 * 128
+    raw = torch.full((128 + B * Hi * Hi * C,), 7.0, device=dev, dtype=torch.bfloat16)   # poison: only the zero line may be read outside
+    raw[:128].zero_()
+    raw[128:].copy_(xb.permute(0, 2, 3, 1).reshape(-1))                               # NHWC
+    wm = torch.zeros(Np, 9 * C, device=dev, dtype=torch.bfloat16)
+    wm[:Cout] = wb.permute(0, 2, 3, 1).reshape(Cout, -1)                              # K ordered (ky, kx, c)
+    bp = torch.zeros(Np, device=dev)
+    bp[:Cout] = bias
+    out = torch.empty(B * Ho * Ho, Np, device=dev)
+    call('mdt_conv3x3_nhwc', raw[128:].data_ptr(), B, Hi, C, up, wm.data_ptr(), bp.data_ptr(), out.data_ptr(), Np, Np, ops.stream_ptr())
+    got = out[:, :Cout].reshape(B, Ho, Ho, Cout).permute(0, 3, 1, 2)
+    err = ((got - ref).abs().max() / ref.abs().max()).item()
+    print(f'conv3x3 implicit GEMM B{B} H{Hi} C{C}->{Cout} up{up}: rel-to-max err {err:.2e}')
+    assert err <= 2e-5  # same bf16 operands, fp32 accumulation both ways
+    assert bool((out[:, Cout:] == 0).all())  # padded output columns: zero weights, zero bias
