@@ -6,6 +6,7 @@ Every counter is averaged per launch and kernel name; derived columns where the 
                 launch.  GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (a 0.78 ms launch reads 1.17e7 = 8 x 1.47e6
                 cycles); SQ_VALU_MFMA_BUSY_CYCLES is the chip total (16 cycles per 16x16x32 bf16 MFMA, checked against
                 SQ_INSTS_VALU_MFMA_MOPS_BF16 and the launch's FLOPs)
+  LDS busy    = SQ_LDS_IDX_ACTIVE / (GRBM_GUI_ACTIVE / 8 x 256 CUs): LDS-array cycles per CU-cycle (bank-conflict cycles included)
   wave states = SQ_WAIT_ANY | SQ_WAIT_INST_ANY | SQ_ACTIVE_INST_ANY as fractions of SQ_WAVE_CYCLES (MI355X_MICROARCH.md:
                 parked on s_waitcnt / barrier | issue stalls | issuing)."""
 import glob
@@ -41,11 +42,12 @@ def main(dirs):
             'stall': None if not wc or g('SQ_WAIT_INST_ANY') is None else g('SQ_WAIT_INST_ANY') / wc,
             'issue': None if not wc or g('SQ_ACTIVE_INST_ANY') is None else g('SQ_ACTIVE_INST_ANY') / wc,
             'lds stall': None if not wc or g('SQ_WAIT_INST_LDS') is None else g('SQ_WAIT_INST_LDS') / wc,
+            'LDS busy': None if not gui or g('SQ_LDS_IDX_ACTIVE') is None else g('SQ_LDS_IDX_ACTIVE') / (gui / 8 * 256),
             'bank conflict': None if not g('SQ_LDS_IDX_ACTIVE') or g('SQ_LDS_BANK_CONFLICT') is None else g('SQ_LDS_BANK_CONFLICT') / g('SQ_LDS_IDX_ACTIVE'),
             'GUI cycles': gui, 'MFMA cycles': g('SQ_VALU_MFMA_BUSY_CYCLES'), 'mfma bf16 mops': g('SQ_INSTS_VALU_MFMA_MOPS_BF16'),
         }))
     rows.sort(key=lambda r: -r[0] * r[2])
-    cols = ['L2 hit', 'MFMA busy', 'wait', 'stall', 'issue', 'lds stall', 'bank conflict', 'GUI cycles', 'MFMA cycles', 'mfma bf16 mops']
+    cols = ['L2 hit', 'MFMA busy', 'wait', 'stall', 'issue', 'lds stall', 'LDS busy', 'bank conflict', 'GUI cycles', 'MFMA cycles', 'mfma bf16 mops']
     print(f"{'kernel':62s} {'n':>5s} " + ' '.join(f'{c:>13s}' for c in cols))
     for _, k, n, d in rows:
         cells = []
