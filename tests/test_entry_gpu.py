@@ -226,3 +226,57 @@ def test_auto_resume_logger_and_in_loop_eval(tmp_path):
     assert log.count('Train Steps/Sec') >= 2
     out3 = T.train_loop(T.parse(base + ['--auto_resume', 'False', '--exp_name', 'r2']))
     assert out3['step'] == 3
+
+
+def test_train_two_ranks_zero1_checkpoint_and_resume(tmp_path):
+    """train.py's N > 1 loop end to end with `train.zero1: true` and `train.grad_wire: bf16` (ZeRO-1 was a
+    library nobody could switch on): two ranks under torch.distributed.run on one device (gloo hook), 4 steps with a
+    checkpoint at 2 -- rank 0 saves alone after the collective consolidate() (a bare state_dict() there would
+    dead-lock) -- then a second launch auto-resumes from it.  The saved optimizer state has the reference's full layout and
+    loads into the plain FusedAdam."""
+    import socket
+    import subprocess
+    import maskdit_amd as M
+    tmp = str(tmp_path)
+    cfg = os.path.join(tmp, 'z.yaml')
+    with open(cfg, 'w') as f:
+        f.write(CFG % ('constant', 'synthetic', 'none'))
+    txt = open(cfg).read().replace('train: {batchsize: 16, grad_accum: 2,', 'train: {zero1: true, grad_wire: bf16, batchsize: 8, grad_accum: 2,')
+    txt = txt.replace('ckpt_every: 3', 'ckpt_every: 2')
+    open(cfg, 'w').write(txt)
+
+    def launch(steps):
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+        s.close()
+        env = dict(os.environ, MDT_BENCH_ONE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+        for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+            env.pop(k, None)
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.join(ROOT, 'train.py'), '--config', cfg, '--results_dir', tmp, '--exp_name', 'z',
+               '--max_num_steps', str(steps)]
+        r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        return r.stdout
+
+    out = launch(4)
+    assert '[ZeRO-1]' in out and 'gradient wire bf16' in out and 'Saved checkpoint' in out
+    ck_dir = os.path.join(tmp, 'z', 'checkpoints')
+    assert sorted(os.listdir(ck_dir)) == ['0000002.pt', '0000004.pt']
+    ck = torch.load(os.path.join(ck_dir, '0000004.pt'), map_location='cpu', weights_only=False)
+    assert ck['opt']['param_groups'][0]['step'] == 4
+    k = 'model.final_layer.linear.weight'
+    assert not torch.equal(ck['model'][k], ck['ema'][k]) and bool(torch.isfinite(ck['ema'][k]).all())
+    # the sharded run's checkpoint has the full (apex) optimizer layout: it loads into the unsharded optimizer
+    net = M.Precond_models['edm'](img_resolution=32, img_channels=4, num_classes=1000, model_type='DiT-S/2', use_decoder=True,
+                                  mae_loss_coef=0.1, pad_cls_token=False).to('cuda')
+    net.load_state_dict(ck['model'])
+    opt = M.FusedAdam(net.parameters(), lr=1e-3)
+    opt.load_state_dict(ck['opt'])
+    m = opt.state[next(p for p in net.parameters() if p.requires_grad)]['exp_avg']
+    nz = sum(int((st['exp_avg'] != 0).any()) for st in opt.state.values())
+    assert nz > 0.5 * len(opt.state), 'most moment tensors of the consolidated checkpoint must be non-zero'
+    out2 = launch(2)  # auto-resume from 0000004.pt
+    assert 'resuming from the latest checkpoint' in out2 and 'steps 4 -> 6' in out2
+    assert '0000006.pt' in os.listdir(ck_dir)

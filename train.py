@@ -176,12 +176,20 @@ def train_loop(args):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    # test hook (as bench.py): MDT_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 over gloo, so that the N > 1 loop (DataParallel,
+    # ZeRO-1 consolidation before rank 0 saves, resume broadcast) can be exercised on a one-GPU box; RCCL needs a device per rank
+    one_dev = os.environ.get('MDT_BENCH_ONE_DEVICE') == '1'
+    if one_dev:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        if one_dev:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
     torch.manual_seed(args.global_seed)  # same seed on every rank, as train.py:67-68
 
     mc, tc = cfg.model, cfg.train
