@@ -293,3 +293,63 @@ def test_vae_decoder_surface_cpu(golden_dir):
         vae.decode(torch.zeros(1, 4, 32, 32))
     with pytest.raises(NotImplementedError):
         vae.encode(torch.zeros(1, 3, 256, 256))
+
+
+def test_get_latest_ckpt_and_logger(tmp_path, capsys):
+    """train.py helpers mirroring utils.py:22-34 (highest-numbered <step>.pt, None when there is none) and
+    utils.py:169-225 (stdout / stderr tee into the experiment's log.txt)."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location('mdt_train_entry', os.path.join(ROOT, 'train.py'))
+    tr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tr)
+    d = tmp_path / 'checkpoints'
+    assert tr.get_latest_ckpt(str(d)) is None          # no directory yet: a fresh run, not an error
+    d.mkdir()
+    assert tr.get_latest_ckpt(str(d)) is None
+    for name in ('0000100.pt', '0002000.pt', '0000500.pt', 'notes.txt', 'best.pt', '0009999.pt.tmp'):
+        (d / name).write_bytes(b'')
+    assert tr.get_latest_ckpt(str(d)) == os.path.join(str(d), '0002000.pt')
+    log = tmp_path / 'log.txt'
+    lg = tr.Logger(str(log))
+    try:
+        print('step 1 loss 0.5')
+        print('a warning', file=sys.stderr)
+    finally:
+        lg.close()
+    assert sys.stdout is not lg and sys.stderr is not lg, 'close() must restore the streams'
+    text = log.read_text()
+    assert 'step 1 loss 0.5' in text and 'a warning' in text
+    lg2 = tr.Logger(str(log))  # append mode: a resumed run keeps the earlier lines
+    try:
+        print('resumed')
+    finally:
+        lg2.close()
+    assert log.read_text().startswith(text) and 'resumed' in log.read_text()
+
+
+def test_zero1_slab_ownership_tiles_every_slab():
+    """ZeRO-1 ownership (maskdit_amd/ddp.py slab_pieces, maskdit_amd/zero.py owned_pieces): for every world size the
+    owned ranges of all ranks tile each slab exactly once, equal pieces are 8-element aligned (16-byte bf16 / 32-byte
+    fp32 boundaries for the collectives) and the remainder (< 8 W elements) stays with the last rank."""
+    from maskdit_amd.ddp import slab_pieces
+    from maskdit_amd.zero import owned_pieces
+    from maskdit_amd.engine import Layout, make_spec
+    slabs = Layout(make_spec('DiT-XL/2', 32, 4, 1000)).slabs
+    for world in (1, 2, 3, 4, 8, 16):
+        for name, (lo, hi) in slabs.items():
+            q, pieces, tail = slab_pieces(lo, hi, world)
+            assert q % 8 == 0 and len(pieces) == world
+            assert all(e - a == q for a, e in pieces) and pieces[0][0] == lo
+            assert tail == (lo + world * q, hi) and 0 <= hi - tail[0] < 8 * world
+        n = max(hi for _, hi in slabs.values())
+        cover = np.zeros(n, dtype=np.int32)
+        for r in range(world):
+            mine = owned_pieces(slabs, world, r)
+            assert all(e > a for a, e in mine)
+            for a, e in mine:
+                cover[a:e] += 1
+        lo_all = min(lo for lo, _ in slabs.values())
+        assert lo_all == 0 and (cover == 1).all(), f'world {world}: ranks must own every element exactly once'
+        sizes = [sum(e - a for a, e in owned_pieces(slabs, world, r)) for r in range(world)]
+        assert max(sizes) - min(sizes) < 8 * world * len(slabs), 'shards are balanced to within the per-slab remainders'
