@@ -29,6 +29,11 @@ int mdt_version(void);
  * phase-pipelined kernel wherever its shape constraints hold.
  * "gemm_tn_variant": 0 = auto, 1 = force the 128x128-tile weight-gradient kernel. */
 int mdt_set_tuning(const char* key, int value);
+/* Test support: fills the LDS of every CU with NaN bit patterns (0x7fc07fc0) so that the NEXT kernel on the stream
+ * finds NaNs wherever it reads LDS it has not (yet) written -- how tests/test_00_kernels_gpu.py makes a missing
+ * s_waitcnt / s_barrier in the LDS-DMA pipelines (the round-3 attention-backward race) deterministic.  `sink4` =
+ * 4 writable device bytes (never written in practice). */
+int mdt_lds_poison(void* sink4, mdt_stream_t stream);
 
 /* ---------------------------------------------------------------- GEMMs (MFMA bf16) ---- */
 

@@ -10,7 +10,10 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmaskdit_hip.so')
+# MASKDIT_HIP_LIB: load ANOTHER build of the same C ABI instead of the in-tree product library -- the experiments build
+# (`make -C maskdit_amd/csrc experiments` -> libmaskdit_hip_exp.so, the timing-decomposition switches of tools/*) or a
+# historical binary a regression test is checked against (tools/experiments/).  Never set on the product path.
+LIB_PATH = os.environ.get('MASKDIT_HIP_LIB') or os.path.join(_HERE, 'libmaskdit_hip.so')
 CSRC = os.path.join(_HERE, 'csrc')
 
 vp = C.c_void_p
@@ -77,6 +80,7 @@ _PROTOS = {
     'mdt_softmax_rows': [vp, vp, i32, i32, f32],
     'mdt_vae_prologue': [vp, vp, vp, vp, i32, i32, f32],
     'mdt_vae_epilogue': [vp, i32, vp, i32, i32, i32],
+    'mdt_lds_poison': [vp],
 }
 # entries without the trailing stream
 _PLAIN = {

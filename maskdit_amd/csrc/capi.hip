@@ -29,22 +29,58 @@ extern "C" int mdt_set_tuning(const char* key, int value) {
   if (!strcmp(key, "gemm_nt_variant")) { g_tuning[MDT_TUNE_GEMM_NT_VARIANT] = value; return MDT_OK; }
   if (!strcmp(key, "attn_qf")) { g_tuning[MDT_TUNE_ATTN_QF] = value; return MDT_OK; }
   if (!strcmp(key, "nt8_group_m")) { g_tuning[MDT_TUNE_NT8_GROUP_M] = value; return MDT_OK; }
-  if (!strcmp(key, "nt8_sched")) { g_tuning[MDT_TUNE_NT8_SCHED] = value; return MDT_OK; }
   if (!strcmp(key, "nt8_stagger")) { g_tuning[MDT_TUNE_NT8_STAGGER] = value; return MDT_OK; }
-  if (!strcmp(key, "nt8_skip_epilogue")) { g_tuning[MDT_TUNE_NT8_SKIP_EPILOGUE] = value; return MDT_OK; }
-  if (!strcmp(key, "tn8_dbg")) { g_tuning[MDT_TUNE_TN8_DBG] = value; return MDT_OK; }
+  if (!strcmp(key, "tn8_dbg")) {  // bits 3-7 (round-2 phase form, tile-order group) give correct results; bits 0-2 skip work
+    if (!MDT_EXP(1) && (value & 7)) {
+      mdt_set_error("set_tuning: tn8_dbg bits 0-2 exist in the experiments build only");
+      return MDT_ERR_ARG;
+    }
+    g_tuning[MDT_TUNE_TN8_DBG] = value;
+    return MDT_OK;
+  }
   if (!strcmp(key, "ln_gate_rowwise")) { g_tuning[MDT_TUNE_LN_GATE_ROWWISE] = value; return MDT_OK; }
-  if (!strcmp(key, "attn_dbg")) { g_tuning[MDT_TUNE_ATTN_DBG] = value; return MDT_OK; }
   if (!strcmp(key, "tn8_wide")) { g_tuning[MDT_TUNE_TN8_WIDE] = value; return MDT_OK; }
-  if (!strcmp(key, "nt8_trickle")) { g_tuning[MDT_TUNE_NT8_TRICKLE] = value; return MDT_OK; }
   if (!strcmp(key, "attn_sp")) { g_tuning[MDT_TUNE_ATTN_SP] = value; return MDT_OK; }
   if (!strcmp(key, "nt8_max_cus")) { g_tuning[MDT_TUNE_NT8_MAX_CUS] = value; return MDT_OK; }
   if (!strcmp(key, "nt8_nf3")) { g_tuning[MDT_TUNE_NT8_NF3] = value; return MDT_OK; }
   if (!strcmp(key, "gemm_tn_variant")) { g_tuning[MDT_TUNE_GEMM_TN_VARIANT] = value; return MDT_OK; }
+#ifdef MDT_EXPERIMENTS  // switches that make kernels skip work (garbage results): libmaskdit_hip_exp.so only
+  if (!strcmp(key, "nt8_sched")) { g_tuning[MDT_TUNE_NT8_SCHED] = value; return MDT_OK; }
+  if (!strcmp(key, "nt8_skip_epilogue")) { g_tuning[MDT_TUNE_NT8_SKIP_EPILOGUE] = value; return MDT_OK; }
+  if (!strcmp(key, "attn_dbg")) { g_tuning[MDT_TUNE_ATTN_DBG] = value; return MDT_OK; }
+  if (!strcmp(key, "nt8_trickle")) { g_tuning[MDT_TUNE_NT8_TRICKLE] = value; return MDT_OK; }
+#else
+  if (!strcmp(key, "nt8_sched") || !strcmp(key, "nt8_skip_epilogue") || !strcmp(key, "attn_dbg") || !strcmp(key, "nt8_trickle")) {
+    mdt_set_error("set_tuning: this key exists in the experiments build only (make experiments; MASKDIT_HIP_LIB)");
+    return MDT_ERR_ARG;
+  }
+#endif
   mdt_set_error("set_tuning: unknown key");
   return MDT_ERR_ARG;
 }
 extern "C" int mdt_version(void) { return 1; }
+
+// ---- LDS poison (test support; include/maskdit_hip.h) ---------------------------------------------------------------
+// Every CU's LDS is left holding NaN bit patterns (0x7fc07fc0 = a quiet NaN as fp32 and as two bf16), so that a kernel
+// that reads an LDS location before its own store / LDS-DMA to it has landed -- a missing wait or barrier -- produces
+// NaNs instead of plausible stale data from the previous launch of the same kernel.  LDS is not cleared between
+// workgroups, and one 160 KiB workgroup per CU (x 4 for the dispatcher's round-robin) touches all of it.
+__global__ __launch_bounds__(512) void lds_poison_kernel(unsigned* sink) {
+  __shared__ unsigned cells[160 * 1024 / 4];
+  for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 512) cells[i] = 0x7fc07fc0u;
+  __syncthreads();
+  // a data-dependent read keeps the stores alive; never true
+  if (cells[(threadIdx.x * 97 + blockIdx.x) % (160 * 1024 / 4)] == 0x12345678u) sink[0] = 1u;
+}
+extern "C" int mdt_lds_poison(void* sink4, mdt_stream_t stream) {
+  MDT_REQUIRE(sink4, "lds_poison: null sink");
+  int dev = 0, cus = 256;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+    cus = prop.multiProcessorCount;
+  hipLaunchKernelGGL(lds_poison_kernel, dim3(4 * cus), dim3(512), 0, (hipStream_t)stream, (unsigned*)sink4);
+  return mdt_check_launch("lds_poison");
+}
 
 #define HIP_TRY(call, what)                                                         \
   do {                                                                              \

@@ -21,6 +21,14 @@ int mdt_check_launch(const char* what);
 // tuning knobs (capi.hip; set through mdt_set_tuning)
 enum { MDT_TUNE_GEMM_NT_VARIANT = 0, MDT_TUNE_GEMM_TN_VARIANT = 1, MDT_TUNE_NT8_SKIP_EPILOGUE = 2, MDT_TUNE_NT8_STAGGER = 3, MDT_TUNE_NT8_GROUP_M = 4, MDT_TUNE_ATTN_QF = 5, MDT_TUNE_NT8_NF3 = 6, MDT_TUNE_NT8_MAX_CUS = 7, MDT_TUNE_ATTN_SP = 8, MDT_TUNE_NT8_TRICKLE = 9, MDT_TUNE_TN8_WIDE = 10, MDT_TUNE_TN8_DBG = 11, MDT_TUNE_LN_GATE_ROWWISE = 12, MDT_TUNE_ATTN_DBG = 13, MDT_TUNE_NT8_SCHED = 14, MDT_TUNE_COUNT = 16 };
 int mdt_get_tuning_int(int key);
+// Timing-decomposition switches that make a kernel skip part of its work (RESULTS ARE GARBAGE) exist only in the
+// experiments build (`make experiments` -> libmaskdit_hip_exp.so, -DMDT_EXPERIMENTS; tools/* load it through
+// MASKDIT_HIP_LIB).  In the product library the conditions below are the constant 0 and mdt_set_tuning refuses the keys.
+#ifdef MDT_EXPERIMENTS
+#define MDT_EXP(cond) (cond)
+#else
+#define MDT_EXP(cond) 0
+#endif
 
 #define MDT_REQUIRE(cond, msg)            \
   do {                                    \

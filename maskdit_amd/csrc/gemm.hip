@@ -293,7 +293,7 @@ extern "C" int mdt_gemm_nt(const mdt_gemm_nt_args* a, mdt_stream_t stream) {
              (((uintptr_t)a->res | (uintptr_t)a->gate) & 15) == 0;
   if (a->epi == MDT_EPI_DGELU || a->epi == MDT_EPI_DSILU) nt8_ok = nt8_ok && a->ldaux % 8 == 0 && ((uintptr_t)a->aux & 15) == 0;  // 16-byte pair loads
   if (nt8_ok) {
-    if (mdt_get_tuning_int(MDT_TUNE_NT8_SKIP_EPILOGUE)) p.epi |= 0x100;
+    if (MDT_EXP(mdt_get_tuning_int(MDT_TUNE_NT8_SKIP_EPILOGUE))) p.epi |= 0x100;  // garbage results: experiments build only
     if (const int stg = mdt_get_tuning_int(MDT_TUNE_NT8_STAGGER)) p.epi |= 0x200 | ((stg < 255 ? stg : 255) << 16);
     const bool can8 = (a->M % 256 == 0);
     const int cus = nt8_num_cus();

@@ -9,8 +9,10 @@ int launch_gemm_nt8_class1(const NTParams& p, int nf, int wr, hipStream_t stream
 int launch_gemm_nt8_class2(const NTParams& p, int nf, int wr, hipStream_t stream);  // GELU / SiLU dual output
 int launch_gemm_nt8_class3(const NTParams& p, int nf, int wr, hipStream_t stream);  // gate * y + residual
 int launch_gemm_nt8_class4(const NTParams& p, int nf, int wr, hipStream_t stream);  // d-activation
+#ifdef MDT_EXPERIMENTS  // gemm_nt8_c5.hip / gemm_nt8_x.hip: part of libmaskdit_hip_exp.so only (`make experiments`)
 int launch_gemm_nt8_class5(const NTParams& p, hipStream_t stream);                  // overlap experiment (E_TRK)
 int launch_gemm_nt8_sched(const NTParams& p, int nf, int sched, hipStream_t stream);  // phase-placement experiments
+#endif
 
 int nt8_num_cus() {
   static int n = 0;
@@ -30,10 +32,12 @@ int nt8_num_cus() {
 int nt8_max_nf(int epi) { return (epi & 0xff) == MDT_EPI_GATE_RES ? 3 : 4; }
 
 int launch_gemm_nt8(const NTParams& p, int nf, int wr, hipStream_t stream) {
+#ifdef MDT_EXPERIMENTS
   if ((p.epi & 0xff) == MDT_EPI_GATE_RES && nf == 3 && wr == 2 && mdt_get_tuning_int(MDT_TUNE_NT8_TRICKLE))
     return launch_gemm_nt8_class5(p, stream);  // timing experiment: outputs are garbage
   const int sched = mdt_get_tuning_int(MDT_TUNE_NT8_SCHED);
   if (sched && (p.epi & 0xff) == MDT_EPI_BF16 && wr == 2 && nf >= 3) return launch_gemm_nt8_sched(p, nf, sched, stream);
+#endif
   switch (p.epi & 0xff) {
     case MDT_EPI_BF16: return launch_gemm_nt8_class0(p, nf, wr, stream);
     case MDT_EPI_F32: return launch_gemm_nt8_class1(p, nf, wr, stream);

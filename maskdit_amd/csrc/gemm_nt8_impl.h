@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
   stamp(2);
 
 
-  if ((p.epi & 0x100) || E == E_TRK) {  // benchmarking aid (mdt_set_tuning "nt8_skip_epilogue"): main loop only
+  if (MDT_EXP(p.epi & 0x100) || E == E_TRK) {  // benchmarking aid (mdt_set_tuning "nt8_skip_epilogue"): main loop only
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll

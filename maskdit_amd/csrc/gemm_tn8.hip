@@ -118,7 +118,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TN8Params p) {
   char* const lds_w = smem + wave * 1024;
 
   auto issue = [&](int slot, int s, int parts = 15) {  // fill ring slot `slot` with contraction rows of phase s
-    if (p.dbg & 4) s &= 7;  // timing experiment: re-read the first 8 slots (cache-resident source)
+    if (MDT_EXP(p.dbg & 4)) s &= 7;  // timing experiment: re-read the first 8 slots (cache-resident source)
     char* base = lds_w + slot * SLOT_BYTES;
     if (parts & 1) glds16(xu + s * x_step + opaque(x_lo0), base);
     if (parts & 2) glds16(xu + s * x_step + opaque(x_lo1), base + 8192);
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TN8Params p) {
   if constexpr ((K) < Cfg::UNROLL) {                                                                    \
     const int ph = g0 + (K);                                                                            \
     if (ph < S) {                                                                                       \
-      const bool do_reads = ph + 1 < S && !(p.dbg & 2), do_dma = ph + NSLOT < S && !(p.dbg & 1);                                      \
+      const bool do_reads = ph + 1 < S && !MDT_EXP(p.dbg & 2), do_dma = ph + NSLOT < S && !MDT_EXP(p.dbg & 1);                                      \
       {                                                                                                 \
         /* half A (1) fragments of the next phase */                                                    \
         if (do_reads) {                                                                                 \
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TN8Params p) {
   if constexpr ((K) < Cfg::UNROLL) {                                                                    \
     const int ph = g0 + (K);                                                                            \
     if (STEADY || ph < S) {                                                                             \
-      const bool do_reads = STEADY || (ph + 1 < S && !(p.dbg & 2)), do_dma = STEADY || (ph + NSLOT < S && !(p.dbg & 1)); \
+      const bool do_reads = STEADY || (ph + 1 < S && !MDT_EXP(p.dbg & 2)), do_dma = STEADY || (ph + NSLOT < S && !MDT_EXP(p.dbg & 1)); \
       _Pragma("unroll") for (int q = 0; q < 4 * YF; ++q) {                                              \
         TN8_MFMA((K) & 1, q / YF, q % YF)                                                               \
         if (q < 4 + YF) { if (do_reads) TN8_FRAG(((K) + 1) & 1, ((K) + 1) % NSLOT, q) }                 \
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TN8Params p) {
   }
   if constexpr (FINE) {
     int g0 = 0;
-    if (!(p.dbg & 3)) {
+    if (!MDT_EXP(p.dbg & 3)) {
       for (; g0 + Cfg::UNROLL + NSLOT <= S; g0 += Cfg::UNROLL) {
         TN8_PHASE_FINE(0, true) TN8_PHASE_FINE(1, true) TN8_PHASE_FINE(2, true) TN8_PHASE_FINE(3, true) TN8_PHASE_FINE(4, true)
         TN8_PHASE_FINE(5, true) TN8_PHASE_FINE(6, true) TN8_PHASE_FINE(7, true) TN8_PHASE_FINE(8, true) TN8_PHASE_FINE(9, true)
@@ -402,6 +402,9 @@ int launch_gemm_tn8(const bf16* A, int lda, const bf16* B, int ldb, int M, int N
   p.colsum_x = (colsum_a && a_is_x && p.tiles_y >= 2) ? colsum_a : nullptr;
   if (colsum_done) *colsum_done = p.colsum_x != nullptr;
   p.dbg = mdt_get_tuning_int(MDT_TUNE_TN8_DBG);
+#ifndef MDT_EXPERIMENTS
+  p.dbg &= ~7;  // bits 0-2 (skip refills / reads, re-read the first slots) produce garbage: experiments build only
+#endif
   // tile order: groups of 2 X tiles, Y fastest -- the 32 concurrent workgroups of an XCD then cover ~5 X tiles x all 6 Y
   // tiles = 2517 distinct operand columns per streamed row instead of 2816 with groups of 8 (fc1 / fc2 weight gradients
   // -3..-7 %, gpurun_out/r3/tn8_group.log); tn8_dbg bits 4-7 override it for A/B runs

@@ -275,7 +275,7 @@ class Engine:
         self._t_tiles = tiles
         self.shadows_dirty = True
         self._plans: Dict[tuple, 'PassPlan'] = {}   # insertion order = LRU order (plan() re-inserts on every hit)
-        self.plan_budget = 0.80                     # fraction of the device memory all cached plans may hold
+        self.plan_headroom = 0.05                   # fraction of the device a new plan leaves free (see plan())
         self.grad_slab_hook: Optional[Callable[[str, int, int], None]] = None  # DP overlap (ddp.py)
         self.ema_applied = None
         LIVE_ENGINES.add(self)
@@ -310,37 +310,73 @@ class Engine:
         (train_utils/helper.py:9-27) changes the exact count nearly every step, but buffers and launch lists only
         depend on the padded count -- the exact one is a run-time argument of the four launches that read it
         (PassPlan.set_valid)."""
+        global _PLAN_CLOCK
         Lv = (L if L is not None else self.sp.T // 2) if masked else None
         key = (B, masked, train, _rup(Lv, 64) if masked else None)
         pl = self._plans.pop(key, None)
         if pl is None:
-            # LRU cache under a memory budget (ADVICE r2: round 2 dropped EVERY training plan whenever another training
-            # shape was requested, so alternating masked / unmasked forwards or a ragged last micro-batch rebuilt ~0.2 GB
-            # per sample of buffers -- and any instrumentation patched onto a plan -- on every call).  A new plan evicts
-            # least-recently-used ones only while the plans' bytes exceed `plan_budget` of the device memory, or while
-            # its own allocation fails; at most 8 shapes are kept.
+            # LRU cache under a DEVICE-wide memory budget.  Round 2 dropped every training plan whenever another shape
+            # was requested; round 3 budgeted each engine against 0.80 of the device on its own, so with two engines
+            # alive (train.py: net + ema; a test process: whatever the previous tests left behind) the second one could
+            # neither see nor evict the first one's plans and died with OutOfMemoryError (ADVICE r3).  Now: what a new
+            # plan needs is compared with what the device really has free (torch.cuda.mem_get_info + the caching
+            # allocator's idle blocks), and the least-recently-used plan of ANY live engine on this device is dropped
+            # until it fits (5 % of the device stays free for the caller's own tensors) or nothing is left to drop.
             while len(self._plans) >= 8:
                 self._plans.pop(next(iter(self._plans)))
             need = PassPlan.estimate_bytes(self.sp, B, masked, train, Lv)
-            budget = self.plan_budget * torch.cuda.get_device_properties(self.device).total_memory
-            while self._plans and sum(p.nbytes for p in self._plans.values()) + need > budget:
-                self._plans.pop(next(iter(self._plans)))
+            while need + self.plan_headroom * _device_total(self.device) > _device_available(self.device):
+                if not _evict_lru_plan(self.device):
+                    break
             while True:
                 try:
                     pl = PassPlan(self, B, masked, train, Lv)
                     break
                 except torch.cuda.OutOfMemoryError:
-                    if not self._plans:
+                    if not _evict_lru_plan(self.device):
                         raise
-                    self._plans.pop(next(iter(self._plans)))
                     torch.cuda.empty_cache()
         elif masked:
             pl.set_valid(Lv)
+        _PLAN_CLOCK += 1
+        pl.last_use = _PLAN_CLOCK
         self._plans[key] = pl  # most recently used = last
         return pl
 
     def release_plans(self):
         self._plans.clear()
+
+
+_PLAN_CLOCK = 0
+
+
+def _device_total(device) -> int:
+    return torch.cuda.get_device_properties(device).total_memory
+
+
+def _device_available(device) -> int:
+    """Bytes a new allocation can get: free device memory + blocks the caching allocator holds but does not use."""
+    free, _ = torch.cuda.mem_get_info(device)
+    return free + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+
+
+def _evict_lru_plan(device) -> bool:
+    """Drop the least-recently-used cached plan among ALL live engines on `device`; False when none is cached.  (A plan a
+    pending backward still refers to stays alive through that reference -- only the cache entry goes.)"""
+    best = None
+    for eng in list(LIVE_ENGINES):
+        if eng.device != torch.device(device):
+            continue
+        for key, pl in eng._plans.items():
+            if best is None or pl.last_use < best[2].last_use:
+                best = (eng, key, pl)
+    if best is None:
+        return False
+    del best[0]._plans[best[1]]
+    for hook in best[2].evict_hooks:  # e.g. the sampler's captured graphs, which replay this plan's launch list
+        hook()
+    best[2].evict_hooks = []
+    return True
 
 
 def _nt(A, lda, Bw, ldb, M, N, K, bias=0, epi=EPI_BF16, out=0, ldo=0, out2=0, ldo2=0, outf=0, ldof=0, res=0, ldres=0,
@@ -370,7 +406,12 @@ class PassPlan:
 
     def __init__(self, eng: Engine, B: int, masked: bool, train: bool, L: Optional[int]):
         sp = eng.sp
-        self.eng, self.B, self.masked, self.train = eng, B, masked, train
+        # the engine caches its plans, so a plan must not own its engine: Engine <-> PassPlan reference cycles kept
+        # 20-240 GB of a dropped model alive until Python's cyclic collector happened to run
+        self._eng_ref = weakref.ref(eng)
+        self.B, self.masked, self.train = B, masked, train
+        self.last_use = 0
+        self.evict_hooks: List[Callable[[], None]] = []  # run when the plan cache drops this plan for memory
         self.T = sp.T
         # Lv = kept tokens per sample (models/maskdit.py:99: int(T * (1 - mask_ratio)), any value that a
         # mask-ratio schedule produces); the encoder runs on L = Lv rounded up to the 64-row tile: the
@@ -391,6 +432,13 @@ class PassPlan:
         self.bwd = Plan()
         self.gen = 0  # forward generation: the saved activations belong to the LAST forward through this plan
         self._build()
+
+    @property
+    def eng(self) -> Engine:
+        e = self._eng_ref()
+        if e is None:
+            raise RuntimeError('maskdit_amd: this plan outlived its Engine (the model was deleted or re-bound)')
+        return e
 
     @property
     def nbytes(self) -> int:
@@ -452,6 +500,10 @@ class PassPlan:
         lab = self.f32('labels', B, sp.num_classes)
         ids32 = self.t('ids32', (B, 2 * T), torch.int32) if self.masked else None
         Fx = self.f32('F', B, sp.C, sp.R, sp.R)
+        # EDMLoss's own buffers (loss.py; 16 KB per sample): allocated here so that they are covered by plan()'s
+        # out-of-memory handling like everything else
+        for nm in ('yn', 'D', 'y'):
+            self.f32(nm, B, sp.C, sp.R, sp.R)
         # ---------------- conditioning path ---------------------------------------------------
         temb = self.b16('temb', Bp, 256)
         h1, a1 = self.b16('h1', Bp, D), self.b16('a1', Bp, D)
@@ -602,11 +654,12 @@ class PassPlan:
         return obj
 
     def _slab(self, name):
-        eng = self.eng
-        lo, hi = eng.lay.slabs[name]
+        ref = self._eng_ref
+        lo, hi = self.eng.lay.slabs[name]
 
         def cb():
-            if eng.grad_slab_hook is not None:
+            eng = ref()
+            if eng is not None and eng.grad_slab_hook is not None:
                 eng.grad_slab_hook(name, lo, hi)
 
         self.bwd.add_callback(cb)

@@ -72,6 +72,7 @@ class FusedAdam(torch.optim.Optimizer):
         have = {p.data_ptr() for p in trainable}
         if want == have:
             self._first = trainable[0]
+            self._trainable = trainable
             self._arena = eng
             self._alloc_moments(eng)
 
@@ -114,15 +115,26 @@ class FusedAdam(torch.optim.Optimizer):
             hyp = (float(group['lr']), float(b1), float(b2), float(group['eps']), float(group['weight_decay']), float(bc1),
                    float(bc2))
             if self._arena is not None and group is self.param_groups[0]:
-                self._step_arena(hyp)
+                # apex skips parameters without a gradient: the one-kernel arena step is only the same thing when
+                # EVERY trainable parameter has one (or none has: nothing to do).  A mixed set -- the caller dropped
+                # single gradients -- takes the per-tensor path for this step.
+                n_none = sum(1 for p in self._trainable if p.grad is None)
+                if n_none == 0:
+                    self._step_arena(hyp)
+                elif n_none < len(self._trainable):
+                    self._step_mixed(group, hyp)
             else:
                 self._step_tensors(group, hyp)
         return loss
 
+    def _step_mixed(self, group, hyp):
+        """Some (not all) gradients of an arena-bound model are None: per-tensor kernels on the parameters that have one."""
+        self._step_tensors(group, hyp)
+
     def _step_arena(self, hyp):
         eng = self._arena
         G = eng.G
-        if G is None or self._first.grad is None:
+        if G is None:
             return  # nothing was back-propagated (apex skips params without grad)
         ema_ptr, decay = None, 0.0
         if self._ema is not None:

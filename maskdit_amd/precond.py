@@ -214,12 +214,14 @@ class EDMPrecond(nn.Module):
         self._engine: Optional[Engine] = None
         self._seen_version = -1
         self._plist = None
+        self._grad_items = None  # (gradient arena, [(parameter, its arena view)]) -- see _prepare_grad_arena
 
     # ---- engine binding ------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
         # .to()/.cuda()/.cpu(): torch re-creates every parameter's storage, so the arena views
         # are re-established afterwards (models/maskdit.py users call `.to(device)`, train.py:131)
         self._engine = None
+        self._grad_items = None
         super()._apply(fn, *a, **k)
         p0 = next(self.parameters())
         if p0.is_cuda:
@@ -247,6 +249,7 @@ class EDMPrecond(nn.Module):
         self._engine = eng
         self._seen_version = -1
         self._plist = None
+        self._grad_items = None
 
     def engine(self) -> Engine:
         if self._engine is None:
@@ -288,17 +291,30 @@ class EDMPrecond(nn.Module):
 
     # ---- gradient plumbing ---------------------------------------------------------------
     def _prepare_grad_arena(self):
-        """Called right before a backward plan runs: the hand-written backward ACCUMULATES
-        into the arena, matching autograd's `.grad +=`.  If the caller dropped the grads
-        (`zero_grad(set_to_none=True)`, train.py:206) the arena is cleared first."""
+        """Called right before a backward plan runs: the hand-written backward ACCUMULATES into the arena, matching
+        autograd's `.grad +=`.  Decided PER PARAMETER (one sentinel tensor used to stand for all of
+        them): a parameter whose `.grad` is None (`zero_grad(set_to_none=True)`, train.py:206, or a user dropping one
+        gradient) gets its arena range cleared and its `.grad` re-pointed at it; a `.grad` that is some other tensor
+        (assigned by the caller) is copied into the arena first and re-pointed, so that accumulation continues from it."""
         eng = self.engine()
         G = eng.ensure_grad()
-        params = self._engine_params()
-        if params and params[0].grad is None:
-            G.zero_()
-            for name, p in self.named_parameters():
-                if p.requires_grad:
-                    p.grad = eng.view(G, name)
+        items = self._grad_items
+        if items is None or items[0] is not G:
+            items = self._grad_items = (G, [(p, eng.view(G, name)) for name, p in self.named_parameters() if p.requires_grad])
+        pairs = items[1]
+        missing = [(p, v) for p, v in pairs if p.grad is None]
+        if len(missing) == len(pairs):
+            G.zero_()  # the usual case: one fill of the whole arena
+        else:
+            for _, v in missing:
+                v.zero_()
+            for p, v in pairs:
+                g = p.grad
+                if g is not None and g.data_ptr() != v.data_ptr():
+                    v.copy_(g)
+                    p.grad = v
+        for p, v in missing:
+            p.grad = v
         return G
 
     # ---- forward -------------------------------------------------------------------------

@@ -15,6 +15,7 @@ forward plan with the step's fp64 state algebra in torch (`_churn_steps`), check
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Dict, Tuple
 
 import torch
@@ -36,12 +37,15 @@ class _GraphedHeun:
     """Captured graphs + persistent state buffers for one (net, batch, cfg?) shape."""
 
     def __init__(self, net: EDMPrecond, B: int, use_cfg: bool, max_steps: int = 1024):
-        self.net, self.B, self.use_cfg = net, B, use_cfg
+        # neither the network nor its engine is OWNED by the graph cache (a module-level dict): a cached graph must not
+        # keep a deleted model's arenas and plans alive
+        self.B, self.use_cfg = B, use_cfg
+        self.sigma_data = float(net.sigma_data)
         sp = net.spec
         dev = next(net.parameters()).device
         self.chw = sp.C * sp.R * sp.R
         self.dup = 2 if use_cfg else 1
-        self.eng = net.engine()
+        self._eng_ref = weakref.ref(net.engine())
         self.pl = self.eng.plan(B * self.dup, False, False, None)
         f64 = dict(device=dev, dtype=torch.float64)
         self.x_hat = torch.zeros(B, self.chw, **f64)
@@ -55,16 +59,20 @@ class _GraphedHeun:
         self.graph_full = self.graph_last = None
         self.captured_cfg = None
 
+    @property
+    def eng(self):
+        return self._eng_ref()
+
     def _eval(self, st, src, which):
         """network evaluation at t_{i+which} of fp64 state `src` -> plan buffer F"""
-        pl, sd = self.pl, float(self.net.sigma_data)
+        pl, sd = self.pl, self.sigma_data
         call('mdt_sampler_prep', src.data_ptr(), self.t_steps.data_ptr(), self.step_idx.data_ptr(), which,
              pl.buf['xin'].data_ptr(), self.sig.data_ptr(), self.B, self.chw, self.dup, sd, st)
         call('mdt_precond_coef', self.sig.data_ptr(), pl.buf['coef'].data_ptr(), self.B * self.dup, sd, st)
         pl.fwd.run(st)
 
     def _record(self, st, cfg_scale, last):
-        sd = float(self.net.sigma_data)
+        sd = self.sigma_data
         Fp = self.pl.buf['F'].data_ptr()
         self._eval(st, self.x_hat, 0)
         call('mdt_sampler_euler', self.x_hat.data_ptr(), Fp, self.t_steps.data_ptr(), self.step_idx.data_ptr(), cfg_scale,
@@ -113,7 +121,15 @@ class _GraphedHeun:
 _CACHE: Dict[Tuple[int, int, bool], _GraphedHeun] = {}
 
 
+def release_graphs():
+    """Destroy every cached sampler graph (and with it the references to the inference plans they replay)."""
+    while _CACHE:
+        _CACHE.popitem()[1].destroy()
+
+
 def _graphed(net: EDMPrecond, B: int, use_cfg: bool) -> _GraphedHeun:
+    for k in [k for k, v in _CACHE.items() if v.eng is None]:  # graphs of models that no longer exist
+        _CACHE.pop(k).destroy()
     key = (id(net.engine()), B, use_cfg)
     g = _CACHE.get(key)
     if g is None or g.eng is not net.engine() or g.pl is not net.engine()._plans.get((B * g.dup, False, False, None)):
@@ -121,6 +137,11 @@ def _graphed(net: EDMPrecond, B: int, use_cfg: bool) -> _GraphedHeun:
             _CACHE.pop(next(iter(_CACHE))).destroy()
         g = _GraphedHeun(net, B, use_cfg)
         _CACHE[key] = g
+
+        def dropped(key=key, ref=weakref.ref(g)):  # the plan cache evicted the plan this graph replays
+            if _CACHE.get(key) is ref() and ref() is not None:
+                _CACHE.pop(key).destroy()
+        g.pl.evict_hooks.append(dropped)
     return g
 
 

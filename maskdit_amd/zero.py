@@ -17,7 +17,7 @@ every rank (engine.py), so sharding is a matter of ranges, not of per-parameter 
     the reference's (apex) layout and load into either optimizer.
 
 The arithmetic per element is the same kernel as the unsharded optimizer: results are bit-identical to FusedAdam on
-the same averaged gradient (tests/test_ddp_gpu.py::test_zero1_matches_unsharded).
+the same averaged gradient (tests/test_20_ddp_gpu.py::test_zero1_matches_unsharded).
 """
 from __future__ import annotations
 
@@ -81,10 +81,14 @@ class ShardedFusedAdam(FusedAdam):
         self._m = torch.zeros(n, device=dev, dtype=torch.float32)
         self._v = torch.zeros(n, device=dev, dtype=torch.float32)
 
+    def _step_mixed(self, group, hyp):
+        raise NotImplementedError('ShardedFusedAdam: every trainable parameter needs a gradient (the moments are sharded by '
+                                  'arena range, not by tensor); some .grad are None')
+
     def _step_arena(self, hyp):
         eng = self._arena
         G = eng.G
-        if G is None or self._first.grad is None:
+        if G is None:
             return
         ema_base, decay, ema_eng = None, 0.0, None
         if self._ema is not None:
