@@ -1115,10 +1115,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dma_kernel(const bf16* __rest
        issued AFTER the item's 9 LDS-DMA pieces + lse + 3 O-fragment loads -- the previous item's NSTORE   \
        stores in the steady state, NOTHING for the peeled first item (tools/check_waits.py counts both     \
        histories in the emitted ISA) */                                                                    \
-    asm volatile("" ::: "memory");                                                                         \
+    asm volatile("; MDT_CHK hand_wait" ::: "memory");                                                      \
     __builtin_amdgcn_s_waitcnt(((VMWAIT) & 15) | (7 << 4) | (15 << 8) | (((VMWAIT) >> 4) << 14)); /* vmcnt(VMWAIT) */ \
     asm volatile("" ::: "memory");                                                                         \
     if (tid < L) LSE_CUR[tid] = lse_r;                                                                     \
+    asm volatile("; MDT_CHK no_dma" ::: "memory"); /* tools/check_waits.py: no LDS-DMA in flight on ANY path */ \
     ATTN_DMA_BARRIER() /* B1: buffer P complete; every wave is done with the other buffer */               \
     const int nxt = item + (int)gridDim.x;                                                                 \
     { /* unconditional (the last item re-fetches itself into the idle buffer): a fetch inside a branch makes  \

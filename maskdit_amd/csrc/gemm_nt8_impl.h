@@ -93,7 +93,7 @@ constexpr int drain_count(int d, int NF, int RPP) {
 // the memory-operation order around it.
 template <int N> __device__ __forceinline__ void wait_vm_lgkm() {
   static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
-  asm volatile("" ::: "memory");
+  asm volatile("; MDT_CHK hand_wait" ::: "memory");  // (a comment in the ISA: tools/check_waits.py audits the immediate that follows)
   __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
   asm volatile("" ::: "memory");
 }
@@ -396,6 +396,7 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
   // the two K-tiles of this output tile were put in flight before the previous tile's epilogue
   // (or just above): everything older -- including that epilogue's stores -- must have retired
   wait_vm_lgkm<0>();
+  asm volatile("; MDT_CHK vm_empty" ::: "memory");  // tools/check_waits.py: nothing in flight at the tile hand-over, on any path
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   stamp(0);

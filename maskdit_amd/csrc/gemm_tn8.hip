@@ -66,7 +66,7 @@ template <int OFF> __device__ __forceinline__ bf16x4 tn8_tr_read(unsigned addr) 
 
 template <int N> __device__ __forceinline__ void tn8_wait() {
   static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");
-  asm volatile("" ::: "memory");
+  asm volatile("; MDT_CHK hand_wait" ::: "memory");  // (a comment in the ISA: tools/check_waits.py audits the immediate that follows)
   __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (0 << 8) | ((N >> 4) << 14));
   asm volatile("" ::: "memory");
 }

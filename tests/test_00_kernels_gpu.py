@@ -436,33 +436,51 @@ def _poison_lds():
 def test_attention_bwd_dma_first_item_stress(B_):
     """the XL/2 encoder attention backward (L 128, hd 72: attn_bwd_dma_kernel, LDS-DMA double buffer with
     hand-counted vmcnt waits) read its first item's dO tile before every wave's LDS-DMA had landed -- timing dependent,
-    green on one box and red on the next.  Here: 50 launches per shape, every one preceded by a launch that leaves NaN bit
-    patterns in ALL of every CU's LDS (so an early read yields NaN, not last launch's identical data) and every other one
-    by a 1 GiB fill that evicts the operands from L2 / Infinity Cache (the LDS-DMA then waits for HBM: the slow-arrival
-    case).  All 50 results must be bit-identical to each other and within the usual tolerance of the fp32 reference.
+    green on one box and red on the next.  Here: 3000 ... 50 launches per shape (0.5 - 0.8 M (sample, head) items each,
+    about what the batch-1024-vs-slices test that caught it executes), every one preceded by a launch that leaves NaN bit
+    patterns in ALL of every CU's LDS (so an early read yields NaN, not last launch's identical data), with the operand
+    tensors cycled through warm / cold / mixed cache states (a 512 MiB fill evicts L2 + Infinity Cache; re-reading some
+    tensors afterwards makes THEIR tiles arrive fast and the others slowly) and a concurrent 1 GiB write on a side
+    stream every fifth launch.  All results must be bit-identical to the first and the first within the usual tolerance
+    of the fp32 reference.
     `make -C maskdit_amd/csrc regress` builds the round-3 wait back in; this test fails on that library
     (profiles/r4_first_item_stress_on_r3_wait.txt)."""
     torch.manual_seed(11)
     L, H, hd = 128, 16, 72
     D = H * hd
+    reps = {16: 3000, 32: 1000, 128: 300, 1024: 50}[B_]  # 768 k / 512 k / 614 k / 819 k item executions
     qkv = bf(torch.randn(B_ * L, 3 * D, device=DEV))
     dout = bf(torch.randn(B_ * L, D, device=DEV))
     out, lse = ops.attn_fwd(qkv, B_, L, H, hd)
-    flush = torch.empty(1 << 28, device=DEV, dtype=torch.float32)
-    first, nbad, nnan = None, 0, 0
-    for rep in range(50):
-        if rep & 1:
+    flush = torch.empty(1 << 27, device=DEV, dtype=torch.float32)   # 512 MiB: twice the Infinity Cache
+    noise = torch.empty(1 << 28, device=DEV, dtype=torch.float32)   # 1 GiB written on a side stream DURING the launch
+    side = torch.cuda.Stream()
+    first = ops.attn_bwd(qkv, out, dout, lse, B_, L, H, hd)
+    nbad = torch.zeros((), device=DEV, dtype=torch.int64)
+    nnan = torch.zeros((), device=DEV, dtype=torch.int64)
+    for rep in range(1, reps):
+        # operand temperature: 0 everything warm, 1 everything cold, 2 dO cold / Q K V O lse warm (the dO tile -- the one
+        # delta is computed from -- then lands long after the other waves' tiles), 3 the reverse
+        mode = rep & 3
+        if mode:
             flush.fill_(float(rep))
+            warm = () if mode == 1 else (qkv, out, lse) if mode == 2 else (dout,)
+            for t in warm:
+                torch.sum(t)
+        if rep % 5 == 0:  # HBM busy with somebody else's traffic while the LDS-DMAs are in flight
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                noise.fill_(1.0)
         _poison_lds()
         dqkv = ops.attn_bwd(qkv, out, dout, lse, B_, L, H, hd)
-        if first is None:
-            first = dqkv
-            continue
-        if not torch.equal(dqkv.view(torch.int16), first.view(torch.int16)):
-            nbad += 1
-            nnan += int(torch.isnan(dqkv.float()).any())
+        diff = (dqkv.view(torch.int16) != first.view(torch.int16)).any()
+        nbad += diff
+        nnan += torch.isnan(dqkv).any() & diff
+        if rep % 5 == 0:
+            torch.cuda.current_stream().wait_stream(side)
+    nbad, nnan = int(nbad), int(nnan)
     assert bool(torch.isfinite(first.float()).all()), 'the first launch produced non-finite gradients'
-    assert nbad == 0, f'{nbad} of 49 repeated launches differ bitwise from the first ({nnan} of them contain NaN)'
+    assert nbad == 0, f'{nbad} of {reps - 1} repeated launches differ bitwise from the first ({nnan} of them contain NaN)'
     # against fp32 SDPA autograd, in chunks of 128 samples
     worst = 0.0
     for lo in range(0, B_, 128):
@@ -474,7 +492,7 @@ def test_attention_bwd_dma_first_item_stress(B_):
         ref = q32.grad.permute(1, 3, 0, 2, 4).reshape(n * L, 3 * D)
         for c in range(3):
             worst = max(worst, err(first[rows, c * D:(c + 1) * D], ref[:, c * D:(c + 1) * D]))
-    print(f'[attn bwd stress B {B_}] 50 launches bit-identical; worst rel-to-max err vs fp32 {worst:.3e}')
+    print(f'[attn bwd stress B {B_}] {reps} launches bit-identical; worst rel-to-max err vs fp32 {worst:.3e}')
     assert worst <= 2e-2
 
 

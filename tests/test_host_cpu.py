@@ -353,3 +353,22 @@ def test_zero1_slab_ownership_tiles_every_slab():
         assert lo_all == 0 and (cover == 1).all(), f'world {world}: ranks must own every element exactly once'
         sizes = [sum(e - a for a, e in owned_pieces(slabs, world, r)) for r in range(world)]
         assert max(sizes) - min(sizes) < 8 * world * len(slabs), 'shards are balanced to within the per-slab remainders'
+
+
+def test_isa_wait_audit():
+    """tools/check_waits.py over the ISA hipcc emits for the product flags: every hand-counted
+    `s_waitcnt vmcnt(N)` / bare `s_barrier` of attn_bwd_dma, gemm_nt8<*> (8- and 4-wave forms, the cross-tile prefetch
+    hand-over, the implicit-GEMM convolution), gemm_tn8<*> and the LayerNorm / 128x128 GEMM kernels is consistent with the
+    instruction stream around it on ALL control-flow paths -- and the same audit FAILS on the round-3 attention wait
+    (`-DMDT_REGRESS_R3_ATTN_WAIT`: the peeled first item reaches the buffer hand-over with six LDS-DMA pieces and four
+    register loads in flight)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('check_waits', os.path.join(ROOT, 'tools', 'check_waits.py'))
+    cw = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cw)
+    assert cw.main([]) == 0, 'the wait audit found a problem in the product build: run `python tools/check_waits.py`'
+    rep = cw.Report()
+    cw.compile_asm('attention.hip', ['MDT_REGRESS_R3_ATTN_WAIT'])
+    cw.check_file('attention.hip', ['MDT_REGRESS_R3_ATTN_WAIT'], rep)
+    assert len(rep.errors) == 1 and 'attn_bwd_dma_kernel<72>' in rep.errors[0] and 'no_dma' in rep.errors[0], rep.errors
+    assert 'DDDDDDLLLL' in rep.errors[0]  # six LDS-DMA pieces + lse + three O fragments behind the 3 guaranteed pieces
