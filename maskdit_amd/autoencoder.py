@@ -185,7 +185,13 @@ class FrozenAutoencoderKL(nn.Module):
             gamma, beta = W[norm + '.weight'], W[norm + '.bias']
         Ho = H << up
         M = B * Ho * Ho
-        if k == 3 and cin % 128 == 0:
+        # the implicit-GEMM kernel's shape domain (mdt_conv3x3_nhwc): power-of-two image sides >= 8, whole 256-row tiles,
+        # 8-bit batch index, 32-bit source offsets; anything else (R = 24 / 40 / 48 latents, a batch of one or two at
+        # R = 8) takes the materialised-im2col GEMM below, which has no shape restrictions (the reference
+        # decoder is size-agnostic)
+        implicit_ok = (k == 3 and cin % 128 == 0 and H >= 8 and (H & (H - 1)) == 0 and M % 256 == 0 and B < 256
+                       and Ho <= 2048 and B * H * H * cin * 2 + 256 < (1 << 32))
+        if implicit_ok:
             # implicit GEMM (round 3): the normalised activation is written ONCE as bf16 NHWC (ksize-1 form of
             # mdt_gn_im2col) behind a 256-byte zero line, the MFMA kernel gathers the nine taps (and the 2x up-sampling)
             # itself -- no im2col matrix (9x the activation bytes per convolution in rounds 1-2)
@@ -262,6 +268,10 @@ class FrozenAutoencoderKL(nn.Module):
         z = z.to(torch.float32).contiguous()
         B, C, R, R2 = z.shape
         assert C == Z_CH and R == R2 and R % 8 == 0, f'latent shape {tuple(z.shape)}'
+        if (R * R) % 128 or R * R > 4096:
+            # the mid-block attention runs its T x T score GEMMs through mdt_gemm_nt (N % 128) and mdt_softmax_rows
+            # (<= 4096 keys): R = 16, 32, 48, 64 (128 .. 512 px images; the shipped configs use 32 and 64)
+            raise NotImplementedError(f'maskdit_amd.autoencoder: latent side {R} unsupported (R * R must be a multiple of 128, <= 4096)')
         st = ops.stream_ptr()
         W = self._weights()
         x = self._buf('x0', (B * R * R, Z_CH), torch.float32)

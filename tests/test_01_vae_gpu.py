@@ -104,6 +104,17 @@ def test_vae_decode_vs_reference_fixture(golden_dir):
     # 64x64 latents (ImageNet-512): runs, finite, right shape
     big = vae.decode(torch.randn(1, 4, 64, 64, device=DEV) * 0.5)
     assert big.shape == (1, 3, 512, 512) and bool(torch.isfinite(big).all())
+    # a latent side that is NOT a power of two (48 -> 384 px): outside the implicit-GEMM convolution's domain, every 3x3
+    # convolution takes the materialised-im2col GEMM (round 3 raised MDT_REQUIRE here); against the oracle
+    z48 = torch.randn(1, 4, 48, 48, generator=torch.Generator().manual_seed(5)) * 0.5
+    img48 = vae.decode(z48.to(DEV))
+    with torch.no_grad():
+        ref48 = VO.vae_decode(P, z48)
+    e48 = _relmax(img48, ref48)
+    print(f'VAE decode 48x48 latent (im2col path) vs oracle: {e48:.3e} of max')
+    assert img48.shape == (1, 3, 384, 384) and e48 <= 2.7e-2
+    with pytest.raises(NotImplementedError):
+        vae.decode(torch.zeros(1, 4, 24, 24, device=DEV))
 
 
 @pytest.mark.parametrize('B,Hi,C,Cout,up', [(2, 16, 128, 128, 0), (1, 32, 256, 128, 1), (4, 8, 512, 512, 0), (2, 16, 128, 3, 1)])

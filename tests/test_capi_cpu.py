@@ -41,3 +41,23 @@ def test_argument_validation_without_gpu(built):
     assert rc != 0 and b'power of two' in built.mdt_last_error()
     rc = built.mdt_attn_fwd(1, 1, 1, 2, 100, 2, 72, 0, None)
     assert rc != 0 and b'multiple of 64' in built.mdt_last_error()
+
+
+def test_experiment_switches_are_not_in_the_product_library(built):
+    """the timing-decomposition switches that make kernels skip work (garbage results) and the
+    experiment kernels behind them exist only in `make experiments` (libmaskdit_hip_exp.so).  The product library
+    refuses the keys and contains neither the E_TRK (class 5) nor the phase-placement (`nt8_sched`) kernels."""
+    import subprocess
+    for key in (b'nt8_sched', b'nt8_skip_epilogue', b'nt8_trickle', b'attn_dbg'):
+        assert built.mdt_set_tuning(key, 1) != 0, key
+        assert b'experiments build' in built.mdt_last_error()
+    for bad in (1, 2, 4, 7):
+        assert built.mdt_set_tuning(b'tn8_dbg', bad) != 0
+    assert built.mdt_set_tuning(b'tn8_dbg', 8) == 0 and built.mdt_set_tuning(b'tn8_dbg', 0) == 0  # the A/B bits give correct results
+    # the device code objects are embedded in the host library: their kernel names appear as plain strings
+    names = subprocess.run(['strings', '-n', '12', _lib.LIB_PATH], capture_output=True, text=True).stdout
+    kernels = set(re.findall(r'_Z15gemm_nt8_kernelILi\dELi\dELi(\d)ELi(\d+)EEv8NTParams', names))
+    assert kernels, 'no gemm_nt8 kernel names found in the library'
+    assert all(cls != '5' for cls, _ in kernels), 'the E_TRK experiment kernel is in the product library'
+    assert {int(s) for _, s in kernels} <= {5, 4101}, f'phase-placement experiment kernels in the product library: {sorted(kernels)}'
+    assert 'nt8x_read_stamps' not in names

@@ -1,4 +1,4 @@
-"""N > 1 path on CPU: world_size-2 `gloo` process groups exercising the data-parallel protocol
+"""N > 1 path on CPU: world_size-2 and world_size-8 `gloo` process groups exercising the data-parallel protocol
 of maskdit_amd/ddp.py (slab-wise asynchronous gradient averaging, no_sync accumulation, rank-0
 parameter broadcast) with a stand-in engine that owns the same flat arenas / slab table as the
 HIP engine.  The arithmetic on the slabs is torch here; on the GPU box the same wrapper runs
@@ -64,9 +64,13 @@ def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
-        from maskdit_amd.engine import make_spec
+        from maskdit_amd.engine import Spec, make_spec
         from maskdit_amd.ddp import DataParallel
-        spec = make_spec('DiT-S/2', 32, 4, 1000)
+        if world <= 2:
+            spec = make_spec('DiT-S/2', 32, 4, 1000)
+        else:  # eight CPU ranks: the same slab structure (9 encoder blocks = two adaLN groups, 2 decoder blocks) at 1/20 of the
+            # bytes, so that the gloo collectives stay in the seconds on an 8-core host
+            spec = Spec('tiny', depth=9, D=128, heads=2, patch=2, R=16, C=4, num_classes=1000, mae=True, Dd=128, ddepth=2, dheads=4)
         eng = FakeEngine(spec)
         eng.P.fill_(float(rank + 1))  # replicas start different: construction must broadcast rank 0's
         dp = DataParallel(FakeModule(eng))
@@ -83,7 +87,7 @@ def _worker(rank, world, port, q):
         eng.fake_backward(rank, step=0.0)
         dp.finish_grad_sync()
         want = idx * 1e-6 * (sum(r + 1 for r in range(world)) / world)
-        assert torch.allclose(eng.G, want, rtol=1e-6, atol=1e-9)
+        assert torch.allclose(eng.G, want, rtol=2e-6, atol=1e-9)
         assert dp.reducer.reduced_elems == n
         # --- gradient accumulation: two local micro-steps under no_sync, the third reduces
         eng.G.zero_()
@@ -114,7 +118,7 @@ def _worker(rank, world, port, q):
                 cover[a:e] += 1
         assert bool((cover == 1).all()), 'the owned pieces of all ranks must tile the arena exactly once'
         for a, e in mine:
-            assert torch.allclose(eng.G[a:e], want[a:e], rtol=1e-6, atol=1e-9)
+            assert torch.allclose(eng.G[a:e], want[a:e], rtol=2e-6, atol=1e-9)
         assert dp.reducer.reduced_elems == n
         dp.reducer.set_zero_sharding(False)
         q.put((rank, 'ok'))
@@ -170,15 +174,18 @@ def test_bf16_gradient_wire_world2():
     assert all(r[1] == 'ok' for r in res), res
 
 
-@pytest.mark.timeout(180)
-def test_grad_slab_allreduce_world2():
+# world 8 = the size BASELINE configs[2] runs at (one rank per GPU of the node): slab coverage, no_sync accumulation and the
+# ZeRO-1 ownership tiling have to hold there too, not only for a pair of ranks
+@pytest.mark.timeout(420)
+@pytest.mark.parametrize('world', [2, 8])
+def test_grad_slab_allreduce_world(world):
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=150) for _ in procs]
+    res = [q.get(timeout=360) for _ in procs]
     for p in procs:
         p.join(30)
     assert all(r[1] == 'ok' for r in res), res

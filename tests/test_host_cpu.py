@@ -326,6 +326,23 @@ def test_get_latest_ckpt_and_logger(tmp_path, capsys):
     finally:
         lg2.close()
     assert log.read_text().startswith(text) and 'resumed' in log.read_text()
+    # the tee still answers what libraries ask a text stream (tqdm / faulthandler / warnings), closing twice is fine
+    lg3 = tr.Logger(str(log))
+    try:
+        assert sys.stdout.isatty() == lg3.stdout.isatty() and sys.stderr.encoding == lg3.stdout.encoding
+    finally:
+        lg3.close()
+        lg3.close()
+    # ... and checkpoints are written atomically / a truncated newest file is skipped on auto-resume
+    import torch
+    tr.save_ckpt_atomic({'step': 100}, str(d / '0000100.pt'))
+    tr.save_ckpt_atomic({'step': 500}, str(d / '0000500.pt'))
+    assert not (d / '0000500.pt.tmp').exists()
+    msgs = []
+    path, ck = tr.load_newest_valid_ckpt(str(d), log=msgs.append)   # 0002000.pt is an empty (truncated) file
+    assert path == os.path.join(str(d), '0000500.pt') and ck == {'step': 500}
+    assert len(msgs) == 1 and '0002000.pt' in msgs[0]
+    assert tr.list_ckpts(str(d))[0].endswith('0002000.pt') and len(tr.list_ckpts(str(d))) == 3
 
 
 def test_zero1_slab_ownership_tiles_every_slab():

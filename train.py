@@ -39,15 +39,40 @@ def strip_compile_prefix(sd):
     return {k.replace('_orig_mod.', ''): v for k, v in sd.items()}
 
 
-def get_latest_ckpt(ckpt_dir):
-    """utils.py:22-34: the highest-numbered `<step>.pt` of a checkpoint directory, or None."""
-    best = -1
+def list_ckpts(ckpt_dir):
+    """Every `<step>.pt` of a checkpoint directory, newest first (files still being written end in `.tmp` and never match)."""
+    steps = []
     if os.path.isdir(ckpt_dir):
         for f in os.listdir(ckpt_dir):
             m = re.fullmatch(r'(\d+)\.pt', f)
             if m:
-                best = max(best, int(m.group(1)))
-    return os.path.join(ckpt_dir, f'{best:07d}.pt') if best >= 0 else None
+                steps.append((int(m.group(1)), f))
+    return [os.path.join(ckpt_dir, f) for _, f in sorted(steps, reverse=True)]
+
+
+def get_latest_ckpt(ckpt_dir):
+    """utils.py:22-34: the highest-numbered `<step>.pt` of a checkpoint directory, or None."""
+    c = list_ckpts(ckpt_dir)
+    return c[0] if c else None
+
+
+def save_ckpt_atomic(obj, path):
+    """Write `<path>.tmp`, then rename: a job killed in the middle of a save leaves the previous checkpoint as the newest
+    complete one instead of a truncated `<step>.pt` that every auto-resume would then crash on."""
+    tmp = path + '.tmp'
+    torch.save(obj, tmp)
+    os.replace(tmp, path)
+
+
+def load_newest_valid_ckpt(ckpt_dir, log=print):
+    """(path, loaded dict) of the newest checkpoint that torch.load accepts; unreadable ones (a truncated file from a kill
+    that predates the atomic save, a half-synced network file system) are skipped with a message.  (None, None) if none."""
+    for path in list_ckpts(ckpt_dir):
+        try:
+            return path, torch.load(path, map_location='cpu', weights_only=False)
+        except Exception as e:  # noqa: BLE001 -- any unpickling / zip error means "not a complete checkpoint"
+            log(f'auto-resume: skipping unreadable checkpoint {path} ({type(e).__name__}: {e})')
+    return None, None
 
 
 class Logger:
@@ -68,7 +93,14 @@ class Logger:
         self.file.flush()
         self.stdout.flush()
 
+    def __getattr__(self, name):
+        # everything else a text stream offers (isatty / fileno / encoding / errors ...: tqdm, faulthandler, warnings and
+        # torch.distributed ask for them) comes from the real stdout
+        return getattr(self.stdout, name)
+
     def close(self):
+        if self.file.closed:
+            return
         self.flush()
         if sys.stdout is self:
             sys.stdout = self.stdout
@@ -172,6 +204,17 @@ def make_batches(cfg, args, dev, rank, world, B):
 
 
 def train_loop(args):
+    """train.py:56-291.  The tee of stdout / stderr into log.txt is undone on EVERY exit path (an exception used to leave
+    sys.stdout hijacked and log.txt open -- in pytest that leaked into the following tests)."""
+    state = {'logger': None}
+    try:
+        return _train_loop(args, state)
+    finally:
+        if state['logger'] is not None:
+            state['logger'].close()
+
+
+def _train_loop(args, state):
     cfg = load_config(args.config)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -202,17 +245,25 @@ def train_loop(args):
     # experiment directory (train.py:85-103): with --ckpt_path (and use_ckpt_path) keep writing into that checkpoint's
     # experiment; otherwise <results_dir>/<exp_name>, resuming from its newest checkpoint if there is one
     resumed = False
+    preloaded = None
     if args.ckpt_path and args.use_ckpt_path and os.path.basename(os.path.dirname(os.path.abspath(args.ckpt_path))) == 'checkpoints':
         exp_dir = os.path.dirname(os.path.dirname(os.path.abspath(args.ckpt_path)))
     else:
         exp_dir = os.path.join(args.results_dir, args.exp_name)
         if args.ckpt_path is None and args.auto_resume:
-            args.ckpt_path = get_latest_ckpt(os.path.join(exp_dir, 'checkpoints'))
+            # RANK 0 picks the checkpoint (the newest one that actually loads) and tells the others: every rank listing the
+            # directory on its own can disagree on a lagging file system, and then resumes from different steps
+            choice = [None]
+            if rank == 0:
+                choice[0], preloaded = load_newest_valid_ckpt(os.path.join(exp_dir, 'checkpoints'))
+            if world > 1:
+                dist.broadcast_object_list(choice, src=0)
+            args.ckpt_path = choice[0]
             resumed = args.ckpt_path is not None
     logger = None
     if rank == 0:
         os.makedirs(os.path.join(exp_dir, 'checkpoints'), exist_ok=True)
-        logger = Logger(os.path.join(exp_dir, 'log.txt'))
+        logger = state['logger'] = Logger(os.path.join(exp_dir, 'log.txt'))
         print(f'Experiment directory created at {exp_dir}', flush=True)
         if resumed:
             print(f'resuming from the latest checkpoint {args.ckpt_path}', flush=True)
@@ -226,7 +277,8 @@ def train_loop(args):
         opt = M.FusedAdam(net.parameters(), lr=tc.lr, adam_w_mode=True, weight_decay=0)
     step0 = 0
     if args.ckpt_path:  # train.py:147-162
-        ck = torch.load(args.ckpt_path, map_location='cpu', weights_only=False)
+        ck = preloaded if preloaded is not None else torch.load(args.ckpt_path, map_location='cpu', weights_only=False)
+        preloaded = None
         net.load_state_dict(strip_compile_prefix(ck['model']), strict=args.use_strict_load)
         ema.load_state_dict(strip_compile_prefix(ck['ema']), strict=args.use_strict_load)
         if args.use_strict_load and 'opt' in ck:
@@ -300,8 +352,8 @@ def train_loop(args):
             if zero1:
                 opt.consolidate()  # COLLECTIVE: moments + EMA gathered so that rank 0 alone can save
             if rank == 0:
-                torch.save({'model': net.state_dict(), 'ema': ema.state_dict(), 'opt': opt.state_dict(), 'args': vars(args)},
-                           os.path.join(exp_dir, 'checkpoints', f'{step:07d}.pt'))
+                save_ckpt_atomic({'model': net.state_dict(), 'ema': ema.state_dict(), 'opt': opt.state_dict(), 'args': vars(args)},
+                                 os.path.join(exp_dir, 'checkpoints', f'{step:07d}.pt'))
                 print(f'Saved checkpoint to {os.path.join(exp_dir, "checkpoints", f"{step:07d}.pt")}', flush=True)
             if world > 1:
                 dist.barrier()
@@ -319,8 +371,6 @@ def train_loop(args):
         dist.barrier()
     if zero1:
         opt.sync_ema()
-    if logger is not None:
-        logger.close()
     return {'net': net, 'ema': ema, 'opt': opt, 'step': step, 'loss': last_loss, 'exp_dir': exp_dir, 'eval': last_eval}
 
 
