@@ -523,26 +523,65 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
 template <int HD>
 struct SpCfg {
   static constexpr int CH = HD / 8;
-  static constexpr int PITCH_CH = CH | 1;          // odd 16-byte-chunk pitch: conflict-free ds_read_b128
+  static constexpr int PITCH_CH = CH | 1;          // odd 16-byte-chunk pitch (the un-split image)
   static constexpr int PITCH = PITCH_CH * 16;
   static constexpr int KSTEPS = AttnCfg<HD>::KSTEPS;
   static constexpr int NFRAG = AttnCfg<HD>::NFRAG;
+  // Round 4 EXPERIMENT, hd 72 (nine 16-byte chunks per row): the tile kept as [L rows x 128 B: chunks 0..7, chunk c of row r at
+  // position c ^ (r & 7)] followed by [L x 16 B: the ninth chunk of every row] -- the same L * 144 bytes.  The 144-byte
+  // rows of rounds 2-3 are conflict-free for 16 CONSECUTIVE lanes, but a ds_read_b128 is served in the lane groups
+  // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (MI355X_MICROARCH.md): every row-fragment read and every transpose
+  // read took twice its LDS cycles (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.39-0.47 in profiles/r3_pmc_counters.txt).
+  // tools/attn_lds_conflicts.py enumerates both images over the hardware's lane groups: 144 / 80 and 160 / 80 LDS cycles
+  // before, 80 / 80 and 80 / 80 now.
+  static constexpr bool SPLIT = (CH == 9);  // ... for tiles of <= 256 rows: sp_split<HD, L>
 };
+// (the L = 512 kernels keep the 144-byte rows: their forward sits at 256 VGPRs, and the per-row XOR of the split image
+// -- addresses that are no longer "base + immediate" -- spilled 187 registers there)
+// MEASURED AND NOT ADOPTED (round 4, gpurun_out/r4 -> profiles/r4_attn_lds_image_ab.txt): the split image does what it
+// says -- SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of attn_bwd_dma_kernel<72> 0.412 -> 0.000, LDS busy 0.40 -> 0.22 -- and
+// the kernels get SLOWER on the same box: encoder backward 721 -> 776 us, forward 264 -> 267 us, the L = 256 / hd 72
+// forward 97 -> 130 us.  The rows' XOR makes every fragment address a per-lane value instead of base + immediate
+// (attn_bwd_dma 208 -> 228 VGPRs, ~2 extra VALU per read), and these kernels are issue- / latency-bound, not LDS-bound
+// (LDS busy 0.40 WITH the conflicts).  The product keeps the 144-byte rows; `make abattn` builds the split image
+// (-DMDT_ATTN_IMAGE_SPLIT -> libmaskdit_hip_attnsplit.so) so that the A/B can be repeated.
+#ifdef MDT_ATTN_IMAGE_SPLIT
+template <int HD, int L> constexpr bool sp_split = SpCfg<HD>::SPLIT && L <= 256;
+#else
+template <int HD, int L> constexpr bool sp_split = false;
+#endif
+
+// byte offset of 16-byte chunk c (0 .. CH-1) of `row` inside an L-row tile
+template <int HD, int L>
+__device__ __forceinline__ int sp_chunk_off(int row, int c) {
+  if constexpr (sp_split<HD, L>) return c < 8 ? row * 128 + ((c ^ (row & 7)) << 4) : L * 128 + row * 16;
+  else return row * SpCfg<HD>::PITCH + c * 16;
+}
 
 // row fragment with the contraction tail (columns >= HD) zeroed in registers
-template <int HD>
+template <int HD, int L>
 __device__ __forceinline__ bf16x8 sp_frag_rows(const char* tile, int row, int s, int g) {
   bf16x8 z;
 #pragma unroll
   for (int e = 0; e < 8; ++e) z[e] = (bf16)0.f;
   const int d0 = 32 * s + 8 * g;
-  return (d0 < HD) ? *(const bf16x8*)(tile + row * SpCfg<HD>::PITCH + (4 * s + g) * 16) : z;
+  return (d0 < HD) ? *(const bf16x8*)(tile + sp_chunk_off<HD, L>(row, 4 * s + g)) : z;
 }
 // transposed fragment (see frag_cols); output rows >= HD of the consumer MFMA are garbage and never stored
-template <int HD>
+template <int HD, int L>
 __device__ __forceinline__ bf16x8 sp_frag_cols(const char* tile, int rbase, int fd, int i16, int g) {
-  const char* q = tile + (rbase + 4 * g + (i16 >> 2)) * SpCfg<HD>::PITCH + (16 * fd + 4 * (i16 & 3)) * 2;
-  return cat4(lds_tr_read(q), lds_tr_read(q + 16 * SpCfg<HD>::PITCH));
+  const int row = rbase + 4 * g + (i16 >> 2);
+  if constexpr (sp_split<HD, L>) {
+    // lane i16 supplies the 8-byte piece (i16 & 3) of columns 16 fd .. + 15 of its row: chunk 2 fd + (piece >> 1), half
+    // piece & 1.  fd = 4 is the ninth chunk (columns 64..71) + eight columns that do not exist: those lanes re-read the
+    // row's ninth chunk (they only feed accumulator rows >= HD).  Row + 16 has the same (row & 7).
+    const int sub = (i16 & 1) << 3;
+    const char* q = (fd < 4) ? tile + row * 128 + (((2 * fd + ((i16 & 3) >> 1)) ^ (row & 7)) << 4) + sub : tile + L * 128 + row * 16 + sub;
+    return cat4(lds_tr_read(q), lds_tr_read(q + (fd < 4 ? 16 * 128 : 16 * 16)));
+  } else {
+    const char* q = tile + row * SpCfg<HD>::PITCH + (16 * fd + 4 * (i16 & 3)) * 2;
+    return cat4(lds_tr_read(q), lds_tr_read(q + 16 * SpCfg<HD>::PITCH));
+  }
 }
 
 // global -> registers -> LDS staging of an [ROWS x HD] tile by 512 threads
@@ -583,7 +622,7 @@ __device__ __forceinline__ void sp_store(const SpRegs<HD, ROWS>& t, char* lds, i
     const int idx = tid + 512 * i;
     if (idx < ROWS * CH) {
       const int r = idx / CH, c = idx - r * CH;
-      *(bf16x8*)(lds + r * SpCfg<HD>::PITCH + c * 16) = t.v[i];
+      *(bf16x8*)(lds + sp_chunk_off<HD, ROWS>(r, c)) = t.v[i];
     }
   }
 }
@@ -644,7 +683,7 @@ __global__ __launch_bounds__(512) void attn_fwd_sp_kernel(const bf16* __restrict
     for (int f = 0; f < L / 16; ++f) {
       s[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < C::KSTEPS; ++ks) s[f] = mfma16(sp_frag_rows<HD>(Ks, 16 * f + i16, ks, g), qf[qi][ks], s[f]);
+      for (int ks = 0; ks < C::KSTEPS; ++ks) s[f] = mfma16(sp_frag_rows<HD, L>(Ks, 16 * f + i16, ks, g), qf[qi][ks], s[f]);
     }
     float mx = -1e30f;
 #pragma unroll
@@ -672,7 +711,7 @@ __global__ __launch_bounds__(512) void attn_fwd_sp_kernel(const bf16* __restrict
     for (int ks = 0; ks < L / 32; ++ks) {
       const bf16x8 pf = pack_pair(s[2 * ks], s[2 * ks + 1]);
 #pragma unroll
-      for (int f = 0; f < C::NFRAG; ++f) o[f] = mfma16(sp_frag_cols<HD>(Vs, 32 * ks, f, i16, g), pf, o[f]);
+      for (int f = 0; f < C::NFRAG; ++f) o[f] = mfma16(sp_frag_cols<HD, L>(Vs, 32 * ks, f, i16, g), pf, o[f]);
     }
     const float inv = 1.f / l_tot;
     bf16* orow = out + ((long)b * L + q) * D + h * HD;
@@ -813,8 +852,8 @@ __global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __res
       bf16x8 kf[C::KSTEPS], vf[C::KSTEPS];
 #pragma unroll
       for (int ks = 0; ks < C::KSTEPS; ++ks) {
-        kf[ks] = sp_frag_rows<HD>(Ks, k0 + i16, ks, g);
-        vf[ks] = sp_frag_rows<HD>(Vs, k0 + i16, ks, g);
+        kf[ks] = sp_frag_rows<HD, L>(Ks, k0 + i16, ks, g);
+        vf[ks] = sp_frag_rows<HD, L>(Vs, k0 + i16, ks, g);
       }
       f32x4 dk[C::NFRAG], dv[C::NFRAG];
 #pragma unroll
@@ -831,8 +870,8 @@ __global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __res
           f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < C::KSTEPS; ++ks) {
-            s = mfma16(sp_frag_rows<HD>(Qs, qb + 16 * f + i16, ks, g), kf[ks], s);
-            dp = mfma16(sp_frag_rows<HD>(dOs, qb + 16 * f + i16, ks, g), vf[ks], dp);
+            s = mfma16(sp_frag_rows<HD, L>(Qs, qb + 16 * f + i16, ks, g), kf[ks], s);
+            dp = mfma16(sp_frag_rows<HD, L>(dOs, qb + 16 * f + i16, ks, g), vf[ks], dp);
           }
           const f32x4 ls = *(const f32x4*)(lse_s + qb + 16 * f + 4 * g);
           const f32x4 dl = *(const f32x4*)(del_s + qb + 16 * f + 4 * g);
@@ -849,8 +888,8 @@ __global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __res
           const bf16x8 dsf = pack_pair(ds[2 * ks], ds[2 * ks + 1]);
 #pragma unroll
           for (int f = 0; f < C::NFRAG; ++f) {
-            dv[f] = mfma16(sp_frag_cols<HD>(dOs, qb + 32 * ks, f, i16, g), pf, dv[f]);
-            dk[f] = mfma16(sp_frag_cols<HD>(Qs, qb + 32 * ks, f, i16, g), dsf, dk[f]);
+            dv[f] = mfma16(sp_frag_cols<HD, L>(dOs, qb + 32 * ks, f, i16, g), pf, dv[f]);
+            dk[f] = mfma16(sp_frag_cols<HD, L>(Qs, qb + 32 * ks, f, i16, g), dsf, dk[f]);
           }
         }
       }
@@ -871,8 +910,8 @@ __global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __res
       bf16x8 qf[C::KSTEPS], dqo[C::KSTEPS];
 #pragma unroll
       for (int ks = 0; ks < C::KSTEPS; ++ks) {
-        qf[ks] = sp_frag_rows<HD>(Qs, q, ks, g);
-        dqo[ks] = sp_frag_rows<HD>(dOs, q, ks, g);
+        qf[ks] = sp_frag_rows<HD, L>(Qs, q, ks, g);
+        dqo[ks] = sp_frag_rows<HD, L>(dOs, q, ks, g);
       }
       const float my_lse = lse_s[q], dl = del_s[q];
       f32x4 dq[C::NFRAG];
@@ -886,8 +925,8 @@ __global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __res
           f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int ks = 0; ks < C::KSTEPS; ++ks) {
-            s = mfma16(sp_frag_rows<HD>(Ks, kb + 16 * f + i16, ks, g), qf[ks], s);
-            dp = mfma16(sp_frag_rows<HD>(Vs, kb + 16 * f + i16, ks, g), dqo[ks], dp);
+            s = mfma16(sp_frag_rows<HD, L>(Ks, kb + 16 * f + i16, ks, g), qf[ks], s);
+            dp = mfma16(sp_frag_rows<HD, L>(Vs, kb + 16 * f + i16, ks, g), dqo[ks], dp);
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -899,7 +938,7 @@ __global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __res
         for (int ks = 0; ks < 2; ++ks) {
           const bf16x8 dsf = pack_pair(ds[2 * ks], ds[2 * ks + 1]);
 #pragma unroll
-          for (int f = 0; f < C::NFRAG; ++f) dq[f] = mfma16(sp_frag_cols<HD>(Ks, kb + 32 * ks, f, i16, g), dsf, dq[f]);
+          for (int f = 0; f < C::NFRAG; ++f) dq[f] = mfma16(sp_frag_cols<HD, L>(Ks, kb + 32 * ks, f, i16, g), dsf, dq[f]);
         }
       }
       bf16* drow = dqkv + ((long)b * L + q) * ld + h * HD;
@@ -935,8 +974,8 @@ __device__ __forceinline__ void attn_bwd_item_math(const char* Qs, const char* K
     bf16x8 kf[C::KSTEPS], vf[C::KSTEPS];
 #pragma unroll
     for (int ks = 0; ks < C::KSTEPS; ++ks) {
-      kf[ks] = sp_frag_rows<HD>(Ks, k0 + i16, ks, g);
-      vf[ks] = sp_frag_rows<HD>(Vs, k0 + i16, ks, g);
+      kf[ks] = sp_frag_rows<HD, L>(Ks, k0 + i16, ks, g);
+      vf[ks] = sp_frag_rows<HD, L>(Vs, k0 + i16, ks, g);
     }
     f32x4 dk[C::NFRAG], dv[C::NFRAG];
 #pragma unroll
@@ -953,8 +992,8 @@ __device__ __forceinline__ void attn_bwd_item_math(const char* Qs, const char* K
         f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < C::KSTEPS; ++ks) {
-          s = mfma16(sp_frag_rows<HD>(Qs, qb + 16 * f + i16, ks, g), kf[ks], s);
-          dp = mfma16(sp_frag_rows<HD>(dOs, qb + 16 * f + i16, ks, g), vf[ks], dp);
+          s = mfma16(sp_frag_rows<HD, L>(Qs, qb + 16 * f + i16, ks, g), kf[ks], s);
+          dp = mfma16(sp_frag_rows<HD, L>(dOs, qb + 16 * f + i16, ks, g), vf[ks], dp);
         }
         const f32x4 ls = *(const f32x4*)(lse_s + qb + 16 * f + 4 * g);
         const f32x4 dl = *(const f32x4*)(del_s + qb + 16 * f + 4 * g);
@@ -971,8 +1010,8 @@ __device__ __forceinline__ void attn_bwd_item_math(const char* Qs, const char* K
         const bf16x8 dsf = pack_pair(ds[2 * ks], ds[2 * ks + 1]);
 #pragma unroll
         for (int f = 0; f < C::NFRAG; ++f) {
-          dv[f] = mfma16(sp_frag_cols<HD>(dOs, qb + 32 * ks, f, i16, g), pf, dv[f]);
-          dk[f] = mfma16(sp_frag_cols<HD>(Qs, qb + 32 * ks, f, i16, g), dsf, dk[f]);
+          dv[f] = mfma16(sp_frag_cols<HD, L>(dOs, qb + 32 * ks, f, i16, g), pf, dv[f]);
+          dk[f] = mfma16(sp_frag_cols<HD, L>(Qs, qb + 32 * ks, f, i16, g), dsf, dk[f]);
         }
       }
     }
@@ -988,8 +1027,8 @@ __device__ __forceinline__ void attn_bwd_item_math(const char* Qs, const char* K
     bf16x8 qf[C::KSTEPS], dqo[C::KSTEPS];
 #pragma unroll
     for (int ks = 0; ks < C::KSTEPS; ++ks) {
-      qf[ks] = sp_frag_rows<HD>(Qs, q, ks, g);
-      dqo[ks] = sp_frag_rows<HD>(dOs, q, ks, g);
+      qf[ks] = sp_frag_rows<HD, L>(Qs, q, ks, g);
+      dqo[ks] = sp_frag_rows<HD, L>(dOs, q, ks, g);
     }
     const float my_lse = lse_s[q], dl = del_s[q];
     f32x4 dq[C::NFRAG];
@@ -1003,8 +1042,8 @@ __device__ __forceinline__ void attn_bwd_item_math(const char* Qs, const char* K
         f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < C::KSTEPS; ++ks) {
-          s = mfma16(sp_frag_rows<HD>(Ks, kb + 16 * f + i16, ks, g), qf[ks], s);
-          dp = mfma16(sp_frag_rows<HD>(Vs, kb + 16 * f + i16, ks, g), dqo[ks], dp);
+          s = mfma16(sp_frag_rows<HD, L>(Ks, kb + 16 * f + i16, ks, g), qf[ks], s);
+          dp = mfma16(sp_frag_rows<HD, L>(Vs, kb + 16 * f + i16, ks, g), dqo[ks], dp);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1016,7 +1055,7 @@ __device__ __forceinline__ void attn_bwd_item_math(const char* Qs, const char* K
       for (int ks = 0; ks < 2; ++ks) {
         const bf16x8 dsf = pack_pair(ds[2 * ks], ds[2 * ks + 1]);
 #pragma unroll
-        for (int f = 0; f < C::NFRAG; ++f) dq[f] = mfma16(sp_frag_cols<HD>(Ks, kb + 32 * ks, f, i16, g), dsf, dq[f]);
+        for (int f = 0; f < C::NFRAG; ++f) dq[f] = mfma16(sp_frag_cols<HD, L>(Ks, kb + 32 * ks, f, i16, g), dsf, dq[f]);
       }
     }
     bf16* drow = dbase + (long)q * ld;
@@ -1066,18 +1105,35 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dma_kernel(const bf16* __rest
   const long ld = 3L * D;
   const int nitems = B * H;
 
-  // ---- LDS-DMA role of this wave: tile tw (0 Q, 1 K, 2 V, 3 dO), half hw; per instruction j the lane's byte offset
-  // inside the (sample, head) slab: chunk idx = hw * 576 + 64 j + lane -> row idx / CH, column chunk idx % CH
+  // ---- LDS-DMA role of this wave: tile tw (0 Q, 1 K, 2 V, 3 dO), rows 64 hw .. 64 hw + 63.  An LDS-DMA instruction
+  // writes 1 KiB of LDS lane-linearly, so the image (SpCfg<72>: 128-byte swizzled rows + the ninth-chunk array) is
+  // produced through the SOURCE addresses: instruction j < 8 fills rows 64 hw + 8 j .. + 7 of the main part -- lane ->
+  // row lane / 8, position lane % 8, which holds chunk (lane % 8) ^ (row & 7) --, instruction 8 the ninth chunk of
+  // the wave's 64 rows (one 16-byte piece per row).
+  static_assert(NDMA == 9, "nine 1-KiB pieces per wave");
   const int tw = wave >> 1, hw = wave & 1;
   const long row_bytes = (tw < 3 ? ld : (long)D) * 2;
   unsigned doff[NDMA];
+  int lds_main, lds_tail;
+  if constexpr (sp_split<HD, L>) {
 #pragma unroll
-  for (int j = 0; j < NDMA; ++j) {
-    const int idx = hw * HALF_CH + 64 * j + lane;
-    const int r = idx / C::CH, c = idx - r * C::CH;
-    doff[j] = (unsigned)(r * row_bytes + c * 16);
+    for (int j = 0; j < 8; ++j) {
+      const int r = 64 * hw + 8 * j + (lane >> 3), c = (lane & 7) ^ (lane >> 3);  // (r & 7) == lane >> 3
+      doff[j] = (unsigned)(r * row_bytes + c * 16);
+    }
+    doff[8] = (unsigned)((64 * hw + lane) * row_bytes + 128);
+    lds_main = tw * TILE + hw * 8192;              // + 1024 j
+    lds_tail = tw * TILE + L * 128 + hw * 1024;
+  } else {  // rows of 144 B (the product image): the wave's 576 chunks are one contiguous LDS range
+#pragma unroll
+    for (int j = 0; j < NDMA; ++j) {
+      const int idx = hw * HALF_CH + 64 * j + lane;
+      const int r = idx / C::CH, c = idx - r * C::CH;
+      doff[j] = (unsigned)(r * row_bytes + c * 16);
+    }
+    lds_main = tw * TILE + hw * HALF_CH * 16;
+    lds_tail = lds_main + 8192;
   }
-  const int lds_off = tw * TILE + hw * HALF_CH * 16;  // + 1024 j
   auto item_src = [&](int item) -> const char* {
     int b, h;
     sp_item_coords(item, B, H, b, h);
@@ -1126,7 +1182,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dma_kernel(const bf16* __rest
          hipcc merge the two vmcnt histories conservatively and wait for the DMA it has just issued */      \
       const int fit = nxt < nitems ? nxt : item;                                                           \
       const char* src = item_src(fit);                                                                     \
-      _Pragma("unroll") for (int j = 0; j < NDMA; ++j) glds16(src + opaque(doff[j]), NXT + lds_off + 1024 * j); \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) glds16(src + opaque(doff[j]), NXT + lds_main + 1024 * j); \
+      glds16(src + opaque(doff[8]), NXT + lds_tail);                                                       \
       int nb, nh;                                                                                          \
       sp_item_coords(fit, B, H, nb, nh);                                                                   \
       lse_r = lse[((long)nb * H + nh) * L + (tid & (L - 1))];                                              \
@@ -1138,7 +1195,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dma_kernel(const bf16* __rest
     { /* delta = rowsum(dO * O) of this wave's queries */                                                  \
       float dl = 0.f;                                                                                      \
       _Pragma("unroll") for (int s2 = 0; s2 < C::KSTEPS; ++s2) {                                           \
-        const bf16x8 dof = sp_frag_rows<HD>(dOs, qrow, s2, g);                                             \
+        const bf16x8 dof = sp_frag_rows<HD, L>(dOs, qrow, s2, g);                                             \
         float part = 0.f;                                                                                  \
         _Pragma("unroll") for (int e = 0; e < 8; ++e) part += bf2f(dof[e]) * bf2f(OF_CUR[s2][e]);          \
         dl += (32 * s2 + 8 * g < HD) ? part : 0.f;                                                         \
@@ -1160,7 +1217,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dma_kernel(const bf16* __rest
   {  // prologue: first item -> buffer 0
     const char* src = item_src(item);
 #pragma unroll
-    for (int j = 0; j < NDMA; ++j) glds16(src + opaque(doff[j]), buf0 + lds_off + 1024 * j);
+    for (int j = 0; j < 8; ++j) glds16(src + opaque(doff[j]), buf0 + lds_main + 1024 * j);
+    glds16(src + opaque(doff[8]), buf0 + lds_tail);
     int b, h;
     sp_item_coords(item, B, H, b, h);
     lse_r = lse[((long)b * H + h) * L + (tid & (L - 1))];
@@ -1261,8 +1319,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_q_res_kernel(const bf16* __re
         f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < C::KSTEPS; ++ks) {
-          sv = mfma16(sp_frag_rows<HD>(Ks, kb + 16 * f + i16, ks, g), qf[ks], sv);
-          dp = mfma16(sp_frag_rows<HD>(Vs, kb + 16 * f + i16, ks, g), dqo[ks], dp);
+          sv = mfma16(sp_frag_rows<HD, L>(Ks, kb + 16 * f + i16, ks, g), qf[ks], sv);
+          dp = mfma16(sp_frag_rows<HD, L>(Vs, kb + 16 * f + i16, ks, g), dqo[ks], dp);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1274,7 +1332,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_q_res_kernel(const bf16* __re
       for (int ks = 0; ks < 2; ++ks) {
         const bf16x8 dsf = pack_pair(ds[2 * ks], ds[2 * ks + 1]);
 #pragma unroll
-        for (int f = 0; f < C::NFRAG; ++f) dq[f] = mfma16(sp_frag_cols<HD>(Ks, kb + 32 * ks, f, i16, g), dsf, dq[f]);
+        for (int f = 0; f < C::NFRAG; ++f) dq[f] = mfma16(sp_frag_cols<HD, L>(Ks, kb + 32 * ks, f, i16, g), dsf, dq[f]);
       }
     }
     bf16* drow = dqkv + ((long)b * L + q) * ld + h * HD;
@@ -1352,8 +1410,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv_res_kernel(const bf16* __r
         f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < C::KSTEPS; ++ks) {
-          sv = mfma16(sp_frag_rows<HD>(Qs, qb + 16 * f + i16, ks, g), kf[ks], sv);
-          dp = mfma16(sp_frag_rows<HD>(dOs, qb + 16 * f + i16, ks, g), vf[ks], dp);
+          sv = mfma16(sp_frag_rows<HD, L>(Qs, qb + 16 * f + i16, ks, g), kf[ks], sv);
+          dp = mfma16(sp_frag_rows<HD, L>(dOs, qb + 16 * f + i16, ks, g), vf[ks], dp);
         }
         const f32x4 ls = *(const f32x4*)(lse_s + qb + 16 * f + 4 * g);
         const f32x4 dl = *(const f32x4*)(del_s + qb + 16 * f + 4 * g);
@@ -1370,8 +1428,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv_res_kernel(const bf16* __r
         const bf16x8 dsf = pack_pair(ds[2 * ks], ds[2 * ks + 1]);
 #pragma unroll
         for (int f = 0; f < C::NFRAG; ++f) {
-          dv[f] = mfma16(sp_frag_cols<HD>(dOs, qb + 32 * ks, f, i16, g), pf, dv[f]);
-          dk[f] = mfma16(sp_frag_cols<HD>(Qs, qb + 32 * ks, f, i16, g), dsf, dk[f]);
+          dv[f] = mfma16(sp_frag_cols<HD, L>(dOs, qb + 32 * ks, f, i16, g), pf, dv[f]);
+          dk[f] = mfma16(sp_frag_cols<HD, L>(Qs, qb + 32 * ks, f, i16, g), dsf, dk[f]);
         }
       }
     }

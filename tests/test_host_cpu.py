@@ -389,3 +389,16 @@ def test_isa_wait_audit():
     cw.check_file('attention.hip', ['MDT_REGRESS_R3_ATTN_WAIT'], rep)
     assert len(rep.errors) == 1 and 'attn_bwd_dma_kernel<72>' in rep.errors[0] and 'no_dma' in rep.errors[0], rep.errors
     assert 'DDDDDDLLLL' in rep.errors[0]  # six LDS-DMA pieces + lse + three O fragments behind the 3 guaranteed pieces
+
+
+def test_attention_lds_image_is_conflict_free():
+    """tools/attn_lds_conflicts.py: the hd-72 tile image of the single-pass attention kernels (SpCfg<72>, round 4) has no
+    bank conflict for either fragment-read pattern under gfx950's lane groups, while the 144-byte rows of rounds 2-3 took
+    1.8x / 2x their LDS cycles (the 0.39-0.47 conflict fraction of profiles/r3_pmc_counters.txt)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('attn_lds_conflicts', os.path.join(ROOT, 'tools', 'attn_lds_conflicts.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    (r, ri), (t, ti), (r0, _), (t0, _) = m.main()
+    assert r == ri and t == ti, 'the split image must be conflict-free'
+    assert r0 > 1.7 * ri and t0 > 1.9 * ti, 'the enumeration should reproduce the measured conflicts of the old image'
