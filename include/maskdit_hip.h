@@ -264,9 +264,12 @@ int mdt_gn_im2col(const float* x, const float* sums, const float* gamma, const f
  * MFMA kernel of mdt_gemm_nt gathers its A operand straight from the NHWC activation; no im2col matrix.  `act`: bf16
  * [B, Hi, Hi, C] (what mdt_gn_im2col writes with ksize 1: GroupNorm + swish applied), C % 128 == 0, Hi a power of two,
  * and THE 256 BYTES IN FRONT OF `act` MUST BE ZERO (the padding taps read them).  W: bf16 [Np, 9 C], Np % 128 == 0;
- * out: fp32 [B * Ho * Ho, ldo]. */
-int mdt_conv3x3_nhwc(const mdt_bf16* act, int B, int Hi, int C, int up, const mdt_bf16* W, const float* bias, float* out,
-                     int ldo, int Np, mdt_stream_t stream);
+ * out: fp32 [B * Ho * Ho, ldo].  Fused epilogue options (round 4; both may be NULL): `res` fp32 [B * Ho * Ho, ldo] is added
+ * to the result (ResnetBlock's `x + h`, autoencoder.py:129); `gn_sums` fp32 [B, 32, 2] (cleared by the CALLER) receives
+ * += (sum, sum of squares) per sample and GroupNorm group of the values stored -- the statistics of the next layer's
+ * Normalize (autoencoder.py:35-36) without a pass of mdt_gn_stats; needs Np == the real channel count and Ho * Ho % 128 == 0. */
+int mdt_conv3x3_nhwc(const mdt_bf16* act, int B, int Hi, int C, int up, const mdt_bf16* W, const float* bias,
+                     const float* res, float* out, int ldo, int Np, float* gn_sums, int gn_groups, mdt_stream_t stream);
 /* out[r, :] = softmax(in[r, :] * scale) as bf16 (AttnBlock, autoencoder.py:188-190) */
 int mdt_softmax_rows(const float* in, mdt_bf16* out, int R, int n, float scale, mdt_stream_t stream);
 /* y[b, p, :] = W (z[b, :, p] / scale_factor) + bias: FrozenAutoencoderKL.decode's rescale + post_quant_conv

@@ -76,7 +76,7 @@ _PROTOS = {
     'mdt_cfg_combine': [vp, f32, vp, i64],
     'mdt_gn_stats': [vp, vp, i32, i32, i32, i32],
     'mdt_gn_im2col': [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32],
-    'mdt_conv3x3_nhwc': [vp, i32, i32, i32, i32, vp, vp, vp, i32, i32],
+    'mdt_conv3x3_nhwc': [vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, vp, i32],
     'mdt_softmax_rows': [vp, vp, i32, i32, f32],
     'mdt_vae_prologue': [vp, vp, vp, vp, i32, i32, f32],
     'mdt_vae_epilogue': [vp, i32, vp, i32, i32, i32],

@@ -18,6 +18,7 @@ CPU fallback.  ddconfig is the reference's (ch 128, ch_mult (1, 2, 4, 4), 2 res 
 z_channels 4, 3 output channels)."""
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -27,6 +28,10 @@ from . import _lib, ops
 from ._lib import call
 
 CH, CH_MULT, NUM_RES_BLOCKS, Z_CH, OUT_CH, GROUPS = 128, (1, 2, 4, 4), 2, 4, 3, 32
+FUSE_EPILOGUE = os.environ.get('MDT_VAE_FUSE', '1') != '0'  # A/B switch (see _conv)
+# widest convolution (output channels) that takes the fused epilogue: it exists for 128-column tiles only (the 256-wide
+# kernel spills with it), so for 256 / 512 channels fusing trades a ~15-20 % slower GEMM against the saved passes
+FUSE_MAX_COUT = int(os.environ.get('MDT_VAE_FUSE_MAXC', '256'))  # measured at batch 64: 128 -> 62.4 ms, 256 -> 61.7, 512 -> 64.4, off -> 67.4
 
 
 def decoder_param_table() -> List[Tuple[str, tuple]]:
@@ -138,6 +143,7 @@ class FrozenAutoencoderKL(nn.Module):
         W = dict(self.named_weights())
         dev = next(self.parameters()).device
         pk = {}
+        self._cout = {}
         for name, p in W.items():
             if name.endswith('.weight') and p.dim() == 4:
                 base = name[:-len('.weight')]
@@ -148,6 +154,7 @@ class FrozenAutoencoderKL(nn.Module):
                 b = torch.zeros(Np, device=dev, dtype=torch.float32)
                 b[:cout] = W[base + '.bias'].detach()
                 pk[base] = (m.to(torch.bfloat16).contiguous(), b, Kp, Np)
+                self._cout[base] = cout
         a = 'decoder.mid.attn_1'
         wp = W[a + '.proj_out.weight'].detach().reshape(W[a + '.proj_out.weight'].shape[0], -1)
         beff = W[a + '.proj_out.bias'].detach() + wp @ W[a + '.v.bias'].detach()
@@ -173,15 +180,20 @@ class FrozenAutoencoderKL(nn.Module):
         return t[:n].view(shape)
 
     # ---- building blocks -----------------------------------------------------------------------
-    def _conv(self, x, B, H, cin, name, k=3, norm=None, swish=False, up=0, slot='a'):
-        """x: fp32 [B*H*H, cin] (NHWC) -> fp32 [B*Ho*Ho, Np]"""
+    def _conv(self, x, B, H, cin, name, k=3, norm=None, swish=False, up=0, slot='a', in_stats=None, res=None, want_stats=False):
+        """x: fp32 [B*H*H, cin] (NHWC) -> (fp32 [B*Ho*Ho, Np], stats).  `in_stats`: GroupNorm sums of x that the
+        PRODUCER of x already accumulated (round 4: the implicit-GEMM convolution's epilogue), else mdt_gn_stats runs;
+        `res`: fp32 [B*Ho*Ho, Np] added to the result inside the epilogue where the implicit-GEMM kernel runs (else by
+        mdt_add_f32); `want_stats`: return the sums [B, 32, 2] of the result when the epilogue can produce them."""
         st = ops.stream_ptr()
         W = self._weights()
         wmat, bias, Kp, Np = self._packed[name]
         sums = gamma = beta = None
         if norm is not None:
-            sums = self._buf('sums', (B, GROUPS, 2), torch.float32)
-            call('mdt_gn_stats', x.data_ptr(), sums.data_ptr(), B, H * H, cin, GROUPS, st)
+            sums = in_stats
+            if sums is None:
+                sums = self._buf('sums', (B, GROUPS, 2), torch.float32)
+                call('mdt_gn_stats', x.data_ptr(), sums.data_ptr(), B, H * H, cin, GROUPS, st)
             gamma, beta = W[norm + '.weight'], W[norm + '.bias']
         Ho = H << up
         M = B * Ho * Ho
@@ -204,27 +216,46 @@ class FrozenAutoencoderKL(nn.Module):
                  gamma.data_ptr() if gamma is not None else None, beta.data_ptr() if beta is not None else None, act.data_ptr(),
                  B, H, H, cin, GROUPS, 1, 0, int(swish), cin, st)
             out = self._buf('out_' + slot, (M, Np), torch.float32)
-            call('mdt_conv3x3_nhwc', act.data_ptr(), B, H, cin, up, wmat.data_ptr(), bias.data_ptr(), out.data_ptr(), Np, Np, st)
-            return out
+            # round 4: the skip connection and the NEXT GroupNorm's statistics come out of the epilogue (128-column tiles;
+            # MDT_VAE_FUSE=0 = the round-3 form: 256-column tiles where they divide, separate add / statistics passes)
+            cout = self._cout[name]
+            cpg = cout // GROUPS if cout % GROUPS == 0 else 0
+            stats = None
+            fuse = FUSE_EPILOGUE and cout <= FUSE_MAX_COUT
+            if fuse and want_stats and cout == Np and cpg >= 4 and (cpg & (cpg - 1)) == 0 and (Ho * Ho) % 128 == 0:
+                stats = self._buf('sums_' + slot, (B, GROUPS, 2), torch.float32)
+                stats.zero_()
+            fres = res if fuse else None
+            call('mdt_conv3x3_nhwc', act.data_ptr(), B, H, cin, up, wmat.data_ptr(), bias.data_ptr(),
+                 fres.data_ptr() if fres is not None else None, out.data_ptr(), Np, Np,
+                 stats.data_ptr() if stats is not None else None, GROUPS, st)
+            if res is not None and fres is None:
+                out = self._add(res, out, slot)
+            return out, stats
         col = self._buf('col', (M, Kp), torch.bfloat16)
         call('mdt_gn_im2col', x.data_ptr(), sums.data_ptr() if sums is not None else None,
              gamma.data_ptr() if gamma is not None else None, beta.data_ptr() if beta is not None else None, col.data_ptr(),
              B, H, H, cin, GROUPS, k, up, int(swish), Kp, st)
         out = self._buf('out_' + slot, (M, Np), torch.float32)
         ops.gemm_nt(col, wmat, bias, ops.EPI_F32, outf=out)
-        return out
+        if res is not None:
+            out = self._add(res, out, slot)
+        return out, None
 
     def _add(self, a, b, slot):
         c = self._buf('sum_' + slot, tuple(a.shape), torch.float32)
         call('mdt_add_f32', a.data_ptr(), b.data_ptr(), c.data_ptr(), a.numel(), ops.stream_ptr())
         return c
 
-    def _res(self, x, B, H, cin, cout, name, slot):
-        h = self._conv(x, B, H, cin, name + '.conv1', norm=name + '.norm1', swish=True, slot='h1')
-        h = self._conv(h, B, H, cout, name + '.conv2', norm=name + '.norm2', swish=True, slot='h2')
+    def _res(self, x, B, H, cin, cout, name, slot, x_stats=None):
+        """ResnetBlock (autoencoder.py:78-140): x + conv2(swish(norm2(conv1(swish(norm1(x)))))) (1x1 shortcut where the widths
+        differ) -> (out, GroupNorm sums of out or None).  The add and both statistics ride on the convolutions' epilogues."""
+        h, h_stats = self._conv(x, B, H, cin, name + '.conv1', norm=name + '.norm1', swish=True, slot='h1', in_stats=x_stats,
+                                want_stats=True)
         if cin != cout:
-            x = self._conv(x, B, H, cin, name + '.nin_shortcut', k=1, slot='sc')
-        return self._add(x, h, slot)
+            x, _ = self._conv(x, B, H, cin, name + '.nin_shortcut', k=1, slot='sc')
+        return self._conv(h, B, H, cout, name + '.conv2', norm=name + '.norm2', swish=True, slot=slot, in_stats=h_stats, res=x,
+                          want_stats=True)
 
     def _attn(self, x, B, H, c, name, slot):
         st = ops.stream_ptr()
@@ -279,21 +310,21 @@ class FrozenAutoencoderKL(nn.Module):
              x.data_ptr(), B, R * R, float(self.scale_factor), st)
         c = CH * CH_MULT[-1]
         H = R
-        x = self._conv(x, B, H, Z_CH, 'decoder.conv_in', slot='x1')
-        x = self._res(x, B, H, c, c, 'decoder.mid.block_1', 'p')
+        x, xs = self._conv(x, B, H, Z_CH, 'decoder.conv_in', slot='x1')
+        x, xs = self._res(x, B, H, c, c, 'decoder.mid.block_1', 'p', xs)
         x = self._attn(x, B, H, c, 'decoder.mid.attn_1', 'q')
-        x = self._res(x, B, H, c, c, 'decoder.mid.block_2', 'p')
+        x, xs = self._res(x, B, H, c, c, 'decoder.mid.block_2', 'p')
         flip = 1  # block_2 left x in slot 'p': the first block of the ladder writes slot 'q'
         for i_level in reversed(range(len(CH_MULT))):
             cout = CH * CH_MULT[i_level]
             for j in range(NUM_RES_BLOCKS + 1):
-                x = self._res(x, B, H, c, cout, f'decoder.up.{i_level}.block.{j}', 'pq'[flip])
+                x, xs = self._res(x, B, H, c, cout, f'decoder.up.{i_level}.block.{j}', 'pq'[flip], xs)
                 flip ^= 1
                 c = cout
             if i_level != 0:
-                x = self._conv(x, B, H, c, f'decoder.up.{i_level}.upsample.conv', up=1, slot='u')
+                x, xs = self._conv(x, B, H, c, f'decoder.up.{i_level}.upsample.conv', up=1, slot='u', want_stats=True)
                 H *= 2
-        y = self._conv(x, B, H, c, 'decoder.conv_out', norm='decoder.norm_out', swish=True, slot='a')
+        y, _ = self._conv(x, B, H, c, 'decoder.conv_out', norm='decoder.norm_out', swish=True, slot='a', in_stats=xs)
         img = torch.empty(B, OUT_CH, H, H, device=z.device, dtype=torch.float32)
         call('mdt_vae_epilogue', y.data_ptr(), y.shape[1], img.data_ptr(), B, H * H, OUT_CH, st)
         return img

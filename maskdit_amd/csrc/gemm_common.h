@@ -25,6 +25,10 @@ struct NTParams {
   // activation [B, Hi, Hi, C] whose 256 bytes in front are zero; row m = output pixel (b, y, x) of an Ho x Ho image
   // (Ho = Hi << conv_up, nearest-neighbour up-sampling folded into the gather), K index = (tap, channel)
   int conv_ho_log2, conv_up, conv_c;
+  // ... and its fused epilogue options (round 4): outf = acc + bias (+ res, the ResnetBlock skip connection, fp32 [M, ldres]);
+  // gn_sums[b, g, 0..1] += (sum, sum of squares) of the stored values of GroupNorm group g = column >> gn_cpg_log2 of
+  // sample b = row >> (2 * conv_ho_log2) -- the statistics the NEXT layer's GroupNorm needs, instead of a separate pass
+  float* gn_sums; int gn_cpg_log2;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {

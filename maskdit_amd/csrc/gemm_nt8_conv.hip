@@ -9,9 +9,13 @@
 
 template __global__ void gemm_nt8_kernel<2, 2, 1, NT8_DEFAULT_SCHED | 4096>(NTParams);
 template __global__ void gemm_nt8_kernel<4, 2, 1, NT8_DEFAULT_SCHED | 4096>(NTParams);
+// the fused epilogue (skip connection + GroupNorm sums, round 4) exists for 128-column tiles only: in the 256-wide kernel
+// (256 VGPRs) it spilled 38-48 registers -- tools/check_waits.py flagged the scratch traffic inside the counted
+// cross-tile pair -- so requests with `res` / `gn_sums` run 128-wide tiles
+template __global__ void gemm_nt8_kernel<2, 2, 1, NT8_DEFAULT_SCHED | 4096 | 8192>(NTParams);
 
 extern "C" int mdt_conv3x3_nhwc(const mdt_bf16* act, int B, int Hi, int C, int up, const mdt_bf16* W, const float* bias,
-                                float* out, int ldo, int Np, mdt_stream_t stream) {
+                                const float* res, float* out, int ldo, int Np, float* gn_sums, int gn_groups, mdt_stream_t stream) {
   MDT_REQUIRE(act && W && out, "conv3x3_nhwc: null operand");
   MDT_REQUIRE(B > 0 && Hi >= 8 && (Hi & (Hi - 1)) == 0, "conv3x3_nhwc: the input size must be a power of two >= 8");
   MDT_REQUIRE(up == 0 || up == 1, "conv3x3_nhwc: up must be 0 or 1 (nearest-neighbour 2x)");
@@ -24,7 +28,19 @@ extern "C" int mdt_conv3x3_nhwc(const mdt_bf16* act, int B, int Hi, int C, int u
   MDT_REQUIRE((long)B * Hi * Hi * C * 2 + 256 < (1L << 32), "conv3x3_nhwc: the activation must stay below 4 GB (32-bit source offsets)");
   const long M = (long)B * Ho * Ho;
   MDT_REQUIRE(M % 256 == 0, "conv3x3_nhwc: B * Ho * Ho must be a multiple of 256");
+  int cpg_log2 = 0;
+  if (gn_sums) {
+    MDT_REQUIRE(gn_groups > 0 && Np % gn_groups == 0, "conv3x3_nhwc: gn_sums needs every output column to be a real channel (Np % groups == 0)");
+    const int cpg = Np / gn_groups;
+    MDT_REQUIRE(cpg >= 4 && (cpg & (cpg - 1)) == 0, "conv3x3_nhwc: channels per GroupNorm group must be a power of two >= 4");
+    MDT_REQUIRE(((long)Ho * Ho) % 128 == 0, "conv3x3_nhwc: gn_sums needs Ho * Ho % 128 == 0 (a wave's 128 rows in one sample)");
+    MDT_REQUIRE(gn_groups == 32, "conv3x3_nhwc: gn_sums is laid out [B, 32, 2]");
+    while ((1 << cpg_log2) < cpg) ++cpg_log2;
+  }
+  MDT_REQUIRE(!res || (((uintptr_t)res & 15) == 0), "conv3x3_nhwc: res must be 16-byte aligned");
   NTParams p = {};
+  p.res = res; p.ldres = ldo;
+  p.gn_sums = gn_sums; p.gn_cpg_log2 = cpg_log2;
   p.A = (const bf16*)((const char*)act - 256);  // offset 0 .. 255 = the zero line the caller keeps in front of the activation
   p.lda = 0;
   p.B = (const bf16*)W; p.ldb = 9 * C;
@@ -36,11 +52,13 @@ extern "C" int mdt_conv3x3_nhwc(const mdt_bf16* act, int B, int Hi, int C, int u
   int hl = 0;
   while ((1 << hl) < Ho) ++hl;
   p.conv_ho_log2 = hl; p.conv_up = up; p.conv_c = C;
-  const int nf = (Np % 256 == 0) ? 4 : 2;
+  const bool fuse = res != nullptr || gn_sums != nullptr;
+  const int nf = (Np % 256 == 0 && !fuse) ? 4 : 2;
   const int ntiles = (p.M / 256) * (Np / (64 * nf));
   const int slots = nt8_num_cus();
   const int grid = ntiles < slots ? ntiles : slots;
-  if (nf == 4) hipLaunchKernelGGL((gemm_nt8_kernel<4, 2, 1, NT8_DEFAULT_SCHED | 4096>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+  if (fuse) hipLaunchKernelGGL((gemm_nt8_kernel<2, 2, 1, NT8_DEFAULT_SCHED | 4096 | 8192>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
+  else if (nf == 4) hipLaunchKernelGGL((gemm_nt8_kernel<4, 2, 1, NT8_DEFAULT_SCHED | 4096>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL((gemm_nt8_kernel<2, 2, 1, NT8_DEFAULT_SCHED | 4096>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p);
   return mdt_check_launch("conv3x3_nhwc");
 }

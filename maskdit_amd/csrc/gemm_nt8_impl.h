@@ -223,6 +223,8 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
   constexpr int QB = SP == 8 ? QLAST : SP == 9 ? QLAST : (8 < QLAST ? 8 : QLAST);
   constexpr bool FJ = NF == 4 && (SP == 5 || SP == 11);
   constexpr bool CONV = (SCHED & 4096) != 0;  // A operand gathered from an NHWC activation (implicit 3x3 convolution)
+  constexpr bool CONV_FUSE = (SCHED & 8192) != 0;  // ... with the fused skip-connection / GroupNorm-statistics epilogue (NF = 2 only: the
+                                                   // 256-wide tile sits at 256 VGPRs and spilled 38-48 registers with it)
   constexpr bool XPF = !(SCHED & 1024) && E != E_TRK;  // cross-tile prefetch inside the last K-tile pair (bit 10 = the round-2 burst, A/B runs)
   // (measured and dropped: non-temporal epilogue stores -- the plain-bf16 epilogue gets 8-17 % SLOWER, gpurun_out/r3/sched4.log)
   constexpr bool X_NODMA = (SCHED & 32) != 0, X_NOREAD = (SCHED & 64) != 0, X_NOBAR = (SCHED & 128) != 0;
@@ -610,6 +612,62 @@ __global__ __launch_bounds__(256 * WR, 2) void gemm_nt8_kernel(NTParams p) {
       if (CS) flush_colsum(csum);
     };
     if (p.colsum) body(T{}); else body(F{});
+  } else if constexpr (E == E_F32 && CONV && CONV_FUSE) {
+    // implicit-GEMM convolution (mdt_conv3x3_nhwc): outf = acc + bias (+ res: the ResnetBlock skip connection,
+    // autoencoder.py:129) and, optionally, the GroupNorm statistics of what is stored (the next layer's Normalize,
+    // autoencoder.py:35-36) -- both used to be separate HBM passes (mdt_add_f32: 12 B / element, mdt_gn_stats: 4)
+    auto body = [&](auto has_res, auto has_gn) {
+      constexpr bool R = decltype(has_res)::value, GN = decltype(has_gn)::value;
+      constexpr int D = 4;  // residual look-ahead in bands (4 NF registers per band)
+      char* fb = ubase(p.outf, p.ldof, 4);
+      const unsigned lf = (unsigned)(fr * p.ldof + 4 * fg) * 4u;
+      char* rb = R ? ubase(p.res, p.ldres, 4) : nullptr;
+      const unsigned lr_ = (unsigned)(fr * p.ldres + 4 * fg) * 4u;
+      f32x4 pre[8][NF];
+      if (R) {
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+          for (int j = 0; j < NF; ++j) pre[i][j] = *(const f32x4*)(band(rb, i, p.ldres, 4) + opaque(lr_) + 64 * j);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      float s1[NF], s2[NF];
+#pragma unroll
+      for (int j = 0; j < NF; ++j) s1[j] = s2[j] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (R && i + D < 8) {
+#pragma unroll
+          for (int j = 0; j < NF; ++j) pre[i + D][j] = *(const f32x4*)(band(rb, i + D, p.ldres, 4) + opaque(lr_) + 64 * j);
+        }
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+          f32x4 y = acc[i][j] + bias[j];
+          if (R) y += pre[i][j];
+          *(f32x4*)(band(fb, i, p.ldof, 4) + opaque(lf) + 64 * j) = y;
+          if (GN) {
+            s1[j] += (y[0] + y[1]) + (y[2] + y[3]);
+            s2[j] += (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]);
+          }
+        }
+      }
+      if (GN) {  // the wave's 128 rows lie in ONE sample (the entry point checks Ho * Ho % 128 == 0)
+        float* gs = p.gn_sums + (long)(em0 >> (2 * p.conv_ho_log2)) * 64;
+#pragma unroll
+        for (int j = 0; j < NF; ++j) {
+          float a = s1[j], b = s2[j];
+          a += __shfl_xor(a, 1, 64); a += __shfl_xor(a, 2, 64); a += __shfl_xor(a, 4, 64); a += __shfl_xor(a, 8, 64);
+          b += __shfl_xor(b, 1, 64); b += __shfl_xor(b, 2, 64); b += __shfl_xor(b, 4, 64); b += __shfl_xor(b, 8, 64);
+          if (fr == 0) {
+            const int grp = (en0 + 16 * j + 4 * fg) >> p.gn_cpg_log2;
+            atomic_add_f32(gs + 2 * grp, a);
+            atomic_add_f32(gs + 2 * grp + 1, b);
+          }
+        }
+      }
+    };
+    if (p.res) { if (p.gn_sums) body(T{}, T{}); else body(T{}, F{}); }
+    else { if (p.gn_sums) body(F{}, T{}); else body(F{}, F{}); }
   } else if constexpr (E == E_F32) {  // outf = acc + bias (the dispatcher sends "also bf16" requests elsewhere)
     char* fb = ubase(p.outf, p.ldof, 4);
     const unsigned lf = (unsigned)(fr * p.ldof + 4 * fg) * 4u;

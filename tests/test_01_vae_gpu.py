@@ -143,9 +143,25 @@ def test_conv3x3_implicit_gemm_vs_conv2d(B, Hi, C, Cout, up):
     bp = torch.zeros(Np, device=dev)
     bp[:Cout] = bias
     out = torch.empty(B * Ho * Ho, Np, device=dev)
-    call('mdt_conv3x3_nhwc', raw[128:].data_ptr(), B, Hi, C, up, wm.data_ptr(), bp.data_ptr(), out.data_ptr(), Np, Np, ops.stream_ptr())
+    call('mdt_conv3x3_nhwc', raw[128:].data_ptr(), B, Hi, C, up, wm.data_ptr(), bp.data_ptr(), None, out.data_ptr(), Np, Np, None, 0,
+         ops.stream_ptr())
     got = out[:, :Cout].reshape(B, Ho, Ho, Cout).permute(0, 3, 1, 2)
     err = ((got - ref).abs().max() / ref.abs().max()).item()
     print(f'conv3x3 implicit GEMM B{B} H{Hi} C{C}->{Cout} up{up}: rel-to-max err {err:.2e}')
     assert err <= 2e-5  # same bf16 operands, fp32 accumulation both ways
     assert bool((out[:, Cout:] == 0).all())  # padded output columns: zero weights, zero bias
+    # round 4: the fused epilogue -- skip connection added, GroupNorm sums of the stored values accumulated
+    # (autoencoder.py:129 `x + h`, :35-36 Normalize = GroupNorm(32)); the plain result above must not change
+    res = torch.randn(B * Ho * Ho, Np, device=dev)
+    fused = torch.empty_like(out)
+    use_gn = Cout == Np and (Ho * Ho) % 128 == 0
+    sums = torch.zeros(B, 32, 2, device=dev) if use_gn else None
+    call('mdt_conv3x3_nhwc', raw[128:].data_ptr(), B, Hi, C, up, wm.data_ptr(), bp.data_ptr(), res.data_ptr(), fused.data_ptr(), Np, Np,
+         sums.data_ptr() if use_gn else None, 32, ops.stream_ptr())
+    assert torch.equal(fused, out + res), 'fused skip connection differs from conv + add'
+    if use_gn:
+        v = fused.double().reshape(B, Ho * Ho, 32, Cout // 32)
+        want = torch.stack([v.sum((1, 3)), (v * v).sum((1, 3))], -1)
+        e = ((sums.double() - want).abs().max() / want.abs().max()).item()
+        print(f'  fused GroupNorm sums: rel-to-max err {e:.2e}')
+        assert e <= 1e-5

@@ -1,5 +1,6 @@
 import sys, os, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _explib  # noqa: F401,E402  (experiments build of the library: attn_dbg is not in the product)
 from maskdit_amd import _lib, ops
 L_ = _lib.lib()
 def t_us(fn, n=10):

@@ -10,6 +10,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _explib  # noqa: F401,E402  (experiments build of the library: the timing switches are not in the product)
 from maskdit_amd import _lib, ops  # noqa: E402
 
 
