@@ -24,7 +24,8 @@ def main(d, flt=''):
             continue
         out.append((rd[1] * rd[0], k, rd[0], rd[1], (dr[1] / rd[1]) if dr else float('nan'), lv[1] / rd[1]))
     for _, k, n, r, fr, lat in sorted(out, reverse=True):
-        print(f'{k[:72]:72s} {n:8d} {r:15.4g} {fr:8.3f} {lat:22.1f}')
+        name = k[:72] if 'reduce_kernel' not in k else '...' + k[k.find('ReduceOp'):][:69]
+        print(f'{name:72s} {n:8d} {r:15.4g} {fr:8.3f} {lat:22.1f}')
 
 
 if __name__ == '__main__':
