@@ -496,6 +496,64 @@ def test_attention_bwd_dma_first_item_stress(B_):
     assert worst <= 2e-2
 
 
+@pytest.mark.parametrize('M,N,K,cus', [(4096, 3072, 1152, 0),      # 192 tiles of 256 x 256: ONE tile per workgroup (prologue -> last pair -> epilogue)
+                                       (8192, 1152, 1152, 0),      # 192 tiles of 256 x 192, one each
+                                       (16384, 1152, 256, 32),     # K = 256: four K-tiles -- the loop body runs once; 12 tiles per workgroup
+                                       (32768, 3456, 1152, 0)])    # 2304 tiles of 256 x 192: 9 per workgroup, cross-tile prefetch every time
+def test_gemm_pipelines_poisoned_lds_stress(M, N, K, cus):
+    """The LDS-DMA pipelines of gemm_nt8 (hand-counted vmcnt per phase, tile-top hand-over, cross-tile prefetch) and gemm_tn8
+    (slot ring) under the conditions that exposed the round-3 attention race: every launch behind mdt_lds_poison (NaN
+    patterns in all of every CU's LDS), operands alternately warm / evicted from L2 + Infinity Cache, 200 launches per
+    shape.  gemm_nt8 must be bit-identical launch to launch (deterministic accumulation order); gemm_tn8 accumulates with
+    fp32 atomics, so it is compared within 1e-5 -- any early LDS read would put NaNs / stale operands into the result.
+    tools/check_waits.py audits the same waits statically."""
+    torch.manual_seed(29)
+    A = bf(torch.randn(M, K, device=DEV) * 0.5)
+    W = bf(torch.randn(N, K, device=DEV) * 0.05)
+    b = torch.randn(N, device=DEV) * 0.1
+    res = torch.randn(M, N, device=DEV)
+    gate = torch.randn(M // 128, N, device=DEV)
+    flush = torch.empty(1 << 27, device=DEV, dtype=torch.float32)
+    lib = _lib.lib()
+    lib.mdt_set_tuning(b'gemm_nt_variant', 2)
+    lib.mdt_set_tuning(b'nt8_max_cus', cus)
+    try:
+        def nt_plain():
+            return ops.gemm_nt(A, W, b, ops.EPI_BF16)[0]
+
+        def nt_gate():
+            o = ops.gemm_nt(A, W, b, ops.EPI_GATE_RES, res=res, gate=gate, gate_ld=N, rows_per_sample=128)
+            return o[2]
+        for name, fn in (('plain', nt_plain), ('gate_res', nt_gate)):
+            if name == 'gate_res' and N % 192:
+                continue  # the gate class has no 256-column tile
+            first = fn()
+            assert bool(torch.isfinite(first.float()).all())
+            nbad = torch.zeros((), device=DEV, dtype=torch.int64)
+            for rep in range(1, 200):
+                if rep & 1:
+                    flush.fill_(float(rep))
+                _poison_lds()
+                nbad += (fn() != first).any()
+            assert int(nbad) == 0, f'gemm_nt8 {name} {M}x{N}x{K}: {int(nbad)} of 199 launches differ from the first'
+    finally:
+        lib.mdt_set_tuning(b'gemm_nt_variant', 0)
+        lib.mdt_set_tuning(b'nt8_max_cus', 0)
+    # weight gradient over the same rows: C[N, K] += W_act^T A  (contraction over M rows)
+    Y = bf(torch.randn(M, N, device=DEV) * 0.25)
+    ref = Y.double().t() @ A.double()
+    worst = 0.0
+    for rep in range(100):
+        if rep & 1:
+            flush.fill_(float(rep))
+        _poison_lds()
+        Cc = torch.zeros(N, K, device=DEV)
+        ops.gemm_tn(Y, A, Cc)
+        worst = max(worst, ((Cc.double() - ref).abs().max() / ref.abs().max()).item())
+    print(f'[gemm stress {M}x{N}x{K}] nt8 bit-identical over 200 launches; tn8 worst rel err over 100 launches {worst:.2e}')
+    assert worst <= 2e-5
+
+
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('B_,L,D', [(3, 128, 1152), (2, 64, 512), (5, 16, 384), (2, 32, 256), (2, 32, 768), (3, 16, 1024)])  # 1..5 quads per lane
 def test_ln_modulate_fwd_bwd(B_, L, D):
