@@ -299,9 +299,11 @@ class EDMPrecond(nn.Module):
         eng = self.engine()
         G = eng.ensure_grad()
         items = self._grad_items
-        if items is None or items[0] is not G:
-            items = self._grad_items = (G, [(p, eng.view(G, name)) for name, p in self.named_parameters() if p.requires_grad])
-        pairs = items[1]
+        if items is None or items[0] is not G:  # (the module tree is fixed: walk it once per gradient arena)
+            items = self._grad_items = (G, [(p, eng.view(G, name)) for name, p in self.named_parameters() if name in eng.lay.off])
+        pairs = [pv for pv in items[1] if pv[0].requires_grad]  # requires_grad may be toggled between steps (finetuning)
+        if not pairs:
+            return G
         missing = [(p, v) for p, v in pairs if p.grad is None]
         if len(missing) == len(pairs):
             G.zero_()  # the usual case: one fill of the whole arena

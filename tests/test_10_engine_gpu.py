@@ -355,6 +355,47 @@ def test_backward_of_an_overwritten_forward_raises(golden_dir):
     assert net.model.blocks[0].attn.qkv.weight.grad is not None
 
 
+def test_gradient_arena_follows_autograd_semantics_per_parameter(golden_dir):
+    """`.grad` of every parameter is a view into one arena and the HIP backward ACCUMULATES into it; what happens to a
+    parameter between two backwards is decided PER PARAMETER, as autograd would (one sentinel tensor
+    used to decide for the whole arena): grad dropped -> starts from zero, grad kept -> accumulates, a foreign tensor
+    assigned as .grad -> accumulation continues from its value; and the fused optimizer skips parameters without a
+    gradient like apex does (the one-kernel arena step only runs when every parameter has one)."""
+    g = _load(golden_dir, 's2_train.npz')
+    cfg, P, net = _build('DiT-S/2', 32, int(g['seed']))
+    params = dict(net.named_parameters())
+    drop = ['model.mask_token', 'model.blocks.3.mlp.fc1.weight']
+    keep = ['model.blocks.3.mlp.fc2.weight', 'model.x_embedder.proj.weight', 'model.blocks.0.adaLN_modulation.1.bias']
+    foreign = 'model.final_layer.linear.bias'
+    net.zero_grad(set_to_none=True)
+    _run_loss(net, g)[0].mean().backward()
+    G1 = {k: params[k].grad.detach().clone() for k in drop + keep + [foreign]}
+    for k in drop:
+        params[k].grad = None
+    params[foreign].grad = torch.full_like(params[foreign], 0.25)
+    _run_loss(net, g)[0].mean().backward()
+    for k in drop:
+        assert _relmax(params[k].grad, G1[k]) <= 1e-5, f'{k}: a dropped gradient must restart from zero'
+    for k in keep:
+        assert _relmax(params[k].grad, 2 * G1[k]) <= 1e-5, f'{k}: a kept gradient must accumulate'
+    assert _relmax(params[foreign].grad, G1[foreign] + 0.25) <= 1e-5, 'a foreign .grad must be accumulated onto'
+    eng = net.engine()
+    assert params[drop[1]].grad.data_ptr() == eng.view(eng.G, drop[1]).data_ptr(), '.grad must point back into the arena'
+    # optimizer: parameters whose grad is None are skipped
+    opt = M.FusedAdam(net.parameters(), lr=1e-3)
+    before = {k: params[k].detach().clone() for k in drop + keep}
+    params[drop[1]].grad = None
+    opt.step()
+    assert torch.equal(params[drop[1]], before[drop[1]]), 'a parameter without gradient must not move'
+    assert not torch.equal(params[keep[0]], before[keep[0]]) and not torch.equal(params[drop[0]], before[drop[0]])
+    # requires_grad toggled after the first backward (finetuning with frozen tensors): its gradient stays untouched
+    params[keep[1]].requires_grad_(False)
+    params[keep[1]].grad = None
+    net.zero_grad(set_to_none=True)
+    _run_loss(net, g)[0].mean().backward()
+    assert params[keep[1]].grad is None and params[keep[0]].grad is not None
+
+
 def test_fails_loudly_off_gpu():
     net = M.Precond_models['edm'](img_resolution=32, img_channels=4, num_classes=1000, model_type='DiT-S/2')
     with pytest.raises(M.MaskDiTLibError):
