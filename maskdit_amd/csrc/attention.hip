@@ -523,7 +523,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
 template <int HD>
 struct SpCfg {
   static constexpr int CH = HD / 8;
-  static constexpr int PITCH_CH = CH | 1;          // odd 16-byte-chunk pitch (the un-split image)
+#ifdef MDT_ATTN_HD32_SWZ  // A/B build (`make abattn32`): hd 32 as UNPADDED 64-byte rows, chunk c of row r at c ^ ((r >> 1) & 3) --
+  // enumerated conflict-free for both fragment-read patterns (the 80-byte rows take 2x the LDS cycles) and 20 % less LDS.
+  // MEASURED, NOT ADOPTED (round 4, profiles/r4_attn_hd32_swizzle_ab.txt; decoder shape B 1024 / L 256): conflicts 0.44-0.47 ->
+  // 0.00, LDS busy 0.48 -> 0.24 (backward), forward 454 -> 432-445 us -- and the backward 1030 -> 1150-1160 us: with the
+  // different address expressions hipcc allocates 166 instead of 216 VGPRs and emits 85 instead of 63 s_waitcnt (less of
+  // the next item's register prefetch stays in flight).  These kernels live or die by hipcc's schedule, not by LDS cycles.
+  static constexpr bool SWZ4 = (CH == 4);
+#else
+  static constexpr bool SWZ4 = false;
+#endif
+  static constexpr int PITCH_CH = SWZ4 ? CH : (CH | 1);  // odd 16-byte-chunk pitch (the un-split image)
   static constexpr int PITCH = PITCH_CH * 16;
   static constexpr int KSTEPS = AttnCfg<HD>::KSTEPS;
   static constexpr int NFRAG = AttnCfg<HD>::NFRAG;
@@ -555,6 +565,7 @@ template <int HD, int L> constexpr bool sp_split = false;
 template <int HD, int L>
 __device__ __forceinline__ int sp_chunk_off(int row, int c) {
   if constexpr (sp_split<HD, L>) return c < 8 ? row * 128 + ((c ^ (row & 7)) << 4) : L * 128 + row * 16;
+  else if constexpr (SpCfg<HD>::SWZ4) return row * 64 + ((c ^ ((row >> 1) & 3)) << 4);  // (staging: any row)
   else return row * SpCfg<HD>::PITCH + c * 16;
 }
 
@@ -565,6 +576,12 @@ __device__ __forceinline__ bf16x8 sp_frag_rows(const char* tile, int row, int s,
 #pragma unroll
   for (int e = 0; e < 8; ++e) z[e] = (bf16)0.f;
   const int d0 = 32 * s + 8 * g;
+  if constexpr (SpCfg<HD>::SWZ4) {
+    // every call site reads row = (multiple of 16) + (lane & 15): the swizzle (row >> 1) & 3 is a LANE constant, so the
+    // address stays [uniform base] + [one per-lane offset] (with the row in the XOR hipcc recomputed it per read)
+    const int swz = ((int)(threadIdx.x & 15) >> 1) & 3;
+    return *(const bf16x8*)(tile + row * 64 + (((4 * s + g) ^ swz) << 4));
+  }
   return (d0 < HD) ? *(const bf16x8*)(tile + sp_chunk_off<HD, L>(row, 4 * s + g)) : z;
 }
 // transposed fragment (see frag_cols); output rows >= HD of the consumer MFMA are garbage and never stored
@@ -578,6 +595,12 @@ __device__ __forceinline__ bf16x8 sp_frag_cols(const char* tile, int rbase, int 
     const int sub = (i16 & 1) << 3;
     const char* q = (fd < 4) ? tile + row * 128 + (((2 * fd + ((i16 & 3) >> 1)) ^ (row & 7)) << 4) + sub : tile + L * 128 + row * 16 + sub;
     return cat4(lds_tr_read(q), lds_tr_read(q + (fd < 4 ? 16 * 128 : 16 * 16)));
+  } else if constexpr (SpCfg<HD>::SWZ4) {
+    // chunk 2 fd + (piece >> 1) of the lane's row, XOR-ed with (row >> 1) & 3 = (2 g + (i16 >> 3)) & 3 for every row base that
+    // is a multiple of 8 (all callers: multiples of 32); row + 16 has the same swizzle
+    const int swz = (2 * g + (i16 >> 3)) & 3;  // a lane constant (rbase % 8 == 0)
+    const char* q = tile + row * 64 + (((2 * fd + ((i16 & 3) >> 1)) ^ swz) << 4) + ((i16 & 1) << 3);
+    return cat4(lds_tr_read(q), lds_tr_read(q + 16 * 64));
   } else {
     const char* q = tile + row * SpCfg<HD>::PITCH + (16 * fd + 4 * (i16 & 3)) * 2;
     return cat4(lds_tr_read(q), lds_tr_read(q + 16 * SpCfg<HD>::PITCH));
