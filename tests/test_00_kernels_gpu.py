@@ -672,7 +672,10 @@ def test_gate_bwd_and_colsum():
 
 
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('B_,T,ratio', [(16, 256, 0.5), (4, 1024, 0.5), (3, 256, 0.75), (2, 64, 0.5)])
+# T >= 64: one wavefront per row, the row in registers, cross-lane exchanges by wavefront shuffles (T / 64 = 1, 2, 4, 8, 16 keys per
+# lane); T = 32: the LDS network kept for rows shorter than a wavefront; B not a multiple of the four rows per workgroup
+@pytest.mark.parametrize('B_,T,ratio', [(16, 256, 0.5), (4, 1024, 0.5), (3, 256, 0.75), (2, 64, 0.5), (5, 128, 0.5), (2, 512, 0.25),
+                                        (3, 32, 0.5), (1023, 256, 0.5)])
 def test_mask_sort_bit_exact(B_, T, ratio):
     torch.manual_seed(6)
     noise = torch.rand(B_, T, device=DEV)
