@@ -402,3 +402,46 @@ def test_attention_lds_image_is_conflict_free():
     (r, ri), (t, ti), (r0, _), (t0, _) = m.main()
     assert r == ri and t == ti, 'the split image must be conflict-free'
     assert r0 > 1.7 * ri and t0 > 1.9 * ti, 'the enumeration should reproduce the measured conflicts of the old image'
+
+
+def test_plan_cache_evicts_least_recently_used_across_engines():
+    """maskdit_amd/engine.py `_evict_lru_plan` (two live engines -- train.py's net and ema -- used to budget and
+    evict on their own, so the second one could die with OutOfMemoryError while the first one's idle 244 GB training plan
+    stayed cached): the victim is the least-recently-used cached plan of ANY live engine on the device, its eviction hooks
+    (the sampler's captured graphs) run, and engines on other devices are left alone.  Host logic only -- stand-in objects."""
+    import types
+    from maskdit_amd import engine as E
+
+    class FakePlan:
+        def __init__(self, last_use, log, name):
+            self.last_use, self.name = last_use, name
+            self.evict_hooks = [lambda: log.append(name)]
+
+    class FakeEngine:
+        def __init__(self, device):
+            self.device = torch.device(device)
+            self._plans = {}
+
+        __hash__ = object.__hash__
+
+    log = []
+    a, b, other = FakeEngine('cuda:0'), FakeEngine('cuda:0'), FakeEngine('cuda:1')
+    a._plans = {'train1024': FakePlan(3, log, 'a.train1024'), 'eval128': FakePlan(9, log, 'a.eval128')}
+    b._plans = {'eval128': FakePlan(5, log, 'b.eval128')}
+    other._plans = {'x': FakePlan(1, log, 'other.x')}       # older than everything, but on another device
+    saved = list(E.LIVE_ENGINES)
+    try:
+        for e in saved:
+            E.LIVE_ENGINES.discard(e)
+        for e in (a, b, other):
+            E.LIVE_ENGINES.add(e)
+        assert E._evict_lru_plan('cuda:0') and log == ['a.train1024'] and 'train1024' not in a._plans
+        assert E._evict_lru_plan(torch.device('cuda', 0)) and log[-1] == 'b.eval128' and not b._plans
+        assert E._evict_lru_plan('cuda:0') and log[-1] == 'a.eval128'
+        assert not E._evict_lru_plan('cuda:0'), 'nothing left on cuda:0'
+        assert list(other._plans) == ['x'], 'plans on other devices must not be touched'
+    finally:
+        for e in (a, b, other):
+            E.LIVE_ENGINES.discard(e)
+        for e in saved:
+            E.LIVE_ENGINES.add(e)
