@@ -97,6 +97,7 @@ def test_full_batch_backward_is_linear_in_slices_xl2_bs1024():
     the persistent multi-tile gemm_nt8 walk in every epilogue class, gemm_tn8 at 131 072 rows and the single-pass
     attention at 16 384 (sample, head) items.  Same bf16 arithmetic per sample both ways: only fp32 accumulation
     order differs, so EVERY parameter gradient must agree to 2e-3 relative L2 (measured worst: see the print)."""
+    torch.cuda.reset_peak_memory_stats()
     cfg, P, net = _build('DiT-XL/2', 32, seed=9)
     B, T = 1024, 256
     images, labels, rnd, noise, mnoise = _bs1024_inputs(18)
@@ -133,7 +134,9 @@ def test_full_batch_backward_is_linear_in_slices_xl2_bs1024():
         pytest.fail(f'{len(bad)} of {len(table)} gradients differ between the full batch and its accumulated slices '
                     f'(tolerance 2e-3 rel L2):\n{lines}')
     assert set(_NAMED_GRADS) <= set(G), sorted(set(_NAMED_GRADS) - set(G))
-    print(f'XL/2 bs1024 backward: {len(G)} gradients, worst full-vs-slices rel L2 {table[0][0]:.3e} at {table[0][1]}')
+    peak, total = torch.cuda.max_memory_allocated(), torch.cuda.get_device_properties(0).total_memory
+    print(f'XL/2 bs1024 backward: {len(G)} gradients, worst full-vs-slices rel L2 {table[0][0]:.3e} at {table[0][1]}; '
+          f'peak allocated {peak / 2**30:.1f} GiB = {peak / total:.1%} of the device')
 
 
 @pytest.mark.skipif(os.environ.get('MASKDIT_SLOW') != '1', reason='~6 min of CPU oracle work: set MASKDIT_SLOW=1')
