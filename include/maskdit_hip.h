@@ -34,6 +34,11 @@ int mdt_set_tuning(const char* key, int value);
  * s_waitcnt / s_barrier in the LDS-DMA pipelines (the round-3 attention-backward race) deterministic.  `sink4` =
  * 4 writable device bytes (never written in practice). */
 int mdt_lds_poison(void* sink4, mdt_stream_t stream);
+/* Test / tool support for the wave-specialised GEMM form (csrc/gemm_nt8o.hip; mdt_set_tuning "nt8_overlap"): its waves
+ * synchronise through LDS counters with BOUNDED spins; *abort_code != 0 means some wave gave up (the results of that
+ * launch are garbage).  stats16 (may be NULL): stall-clock sums of its STATS launches (experiments build).  HOST
+ * pointers; synchronises the device; reset != 0 clears both afterwards. */
+int mdt_nt8o_report(unsigned* abort_code, unsigned long long* stats16, int reset);
 
 /* ---------------------------------------------------------------- GEMMs (MFMA bf16) ---- */
 

@@ -93,6 +93,7 @@ _PLAIN = {
     'mdt_event_elapsed_ms': [vp, vp, C.POINTER(f32)],
     'mdt_event_destroy': [vp],
     'mdt_set_tuning': [C.c_char_p, i32],
+    'mdt_nt8o_report': [C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), i32],
 }
 EXPORTED = sorted(list(_PROTOS) + list(_PLAIN) + ['mdt_last_error', 'mdt_version'])
 

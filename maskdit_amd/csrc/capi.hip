@@ -44,6 +44,16 @@ extern "C" int mdt_set_tuning(const char* key, int value) {
   if (!strcmp(key, "nt8_max_cus")) { g_tuning[MDT_TUNE_NT8_MAX_CUS] = value; return MDT_OK; }
   if (!strcmp(key, "nt8_nf3")) { g_tuning[MDT_TUNE_NT8_NF3] = value; return MDT_OK; }
   if (!strcmp(key, "gemm_tn_variant")) { g_tuning[MDT_TUNE_GEMM_TN_VARIANT] = value; return MDT_OK; }
+  if (!strcmp(key, "nt8_overlap")) {  // 0 / 1 / 2 (gemm.hip); bits 4.. = timing-decomposition switches of gemm_nt8o.hip
+#ifndef MDT_EXPERIMENTS
+    if (value & ~7) {
+      mdt_set_error("set_tuning: nt8_overlap debug bits exist in the experiments build only");
+      return MDT_ERR_ARG;
+    }
+#endif
+    g_tuning[MDT_TUNE_NT8_OVERLAP] = value;
+    return MDT_OK;
+  }
 #ifdef MDT_EXPERIMENTS  // switches that make kernels skip work (garbage results): libmaskdit_hip_exp.so only
   if (!strcmp(key, "nt8_sched")) { g_tuning[MDT_TUNE_NT8_SCHED] = value; return MDT_OK; }
   if (!strcmp(key, "nt8_skip_epilogue")) { g_tuning[MDT_TUNE_NT8_SKIP_EPILOGUE] = value; return MDT_OK; }

@@ -19,7 +19,7 @@ void mdt_set_error(const char* msg);
 int mdt_check_launch(const char* what);
 
 // tuning knobs (capi.hip; set through mdt_set_tuning)
-enum { MDT_TUNE_GEMM_NT_VARIANT = 0, MDT_TUNE_GEMM_TN_VARIANT = 1, MDT_TUNE_NT8_SKIP_EPILOGUE = 2, MDT_TUNE_NT8_STAGGER = 3, MDT_TUNE_NT8_GROUP_M = 4, MDT_TUNE_ATTN_QF = 5, MDT_TUNE_NT8_NF3 = 6, MDT_TUNE_NT8_MAX_CUS = 7, MDT_TUNE_ATTN_SP = 8, MDT_TUNE_NT8_TRICKLE = 9, MDT_TUNE_TN8_WIDE = 10, MDT_TUNE_TN8_DBG = 11, MDT_TUNE_LN_GATE_ROWWISE = 12, MDT_TUNE_ATTN_DBG = 13, MDT_TUNE_NT8_SCHED = 14, MDT_TUNE_COUNT = 16 };
+enum { MDT_TUNE_GEMM_NT_VARIANT = 0, MDT_TUNE_GEMM_TN_VARIANT = 1, MDT_TUNE_NT8_SKIP_EPILOGUE = 2, MDT_TUNE_NT8_STAGGER = 3, MDT_TUNE_NT8_GROUP_M = 4, MDT_TUNE_ATTN_QF = 5, MDT_TUNE_NT8_NF3 = 6, MDT_TUNE_NT8_MAX_CUS = 7, MDT_TUNE_ATTN_SP = 8, MDT_TUNE_NT8_TRICKLE = 9, MDT_TUNE_TN8_WIDE = 10, MDT_TUNE_TN8_DBG = 11, MDT_TUNE_LN_GATE_ROWWISE = 12, MDT_TUNE_ATTN_DBG = 13, MDT_TUNE_NT8_SCHED = 14, MDT_TUNE_NT8_OVERLAP = 15, MDT_TUNE_COUNT = 16 };
 int mdt_get_tuning_int(int key);
 // Timing-decomposition switches that make a kernel skip part of its work (RESULTS ARE GARBAGE) exist only in the
 // experiments build (`make experiments` -> libmaskdit_hip_exp.so, -DMDT_EXPERIMENTS; tools/* load it through

@@ -295,6 +295,14 @@ extern "C" int mdt_gemm_nt(const mdt_gemm_nt_args* a, mdt_stream_t stream) {
   if (nt8_ok) {
     if (MDT_EXP(mdt_get_tuning_int(MDT_TUNE_NT8_SKIP_EPILOGUE))) p.epi |= 0x100;  // garbage results: experiments build only
     if (const int stg = mdt_get_tuning_int(MDT_TUNE_NT8_STAGGER)) p.epi |= 0x200 | ((stg < 255 ? stg : 255) << 16);
+    // "nt8_overlap": 1 = the wave-specialised form (gemm_nt8o.hip: fused epilogue under the next tile's K loop) for the
+    // epilogue classes that carry HBM traffic beyond one bf16 output (GELU / SiLU pairs, gate * y + residual); 2 = also
+    // for the plain bf16 epilogue; 4 = three loader waves + one epilogue wave instead of 2 + 2; bits 4.. = its
+    // timing-decomposition switches (experiments build)
+    if (const int ov = mdt_get_tuning_int(MDT_TUNE_NT8_OVERLAP)) {
+      if (nt8o_eligible(p) && ((ov & 2) || a->epi != MDT_EPI_BF16))
+        return launch_gemm_nt8o(p, (ov & 4) ? 3 : 2, MDT_EXP(ov >> 4), (hipStream_t)stream);
+    }
     const bool can8 = (a->M % 256 == 0);
     const int cus = nt8_num_cus();
     // column tile: 256 (NF = 4) where the epilogue class has it, else 192, else 128; "nt8_nf3" prefers 192-column

@@ -191,5 +191,7 @@ template <int CW> __device__ __forceinline__ void nt_colsum_flush(const NTParams
 int launch_gemm_nt8(const NTParams& p, int nf, int wr, hipStream_t stream);
 int nt8_num_cus();
 int nt8_max_nf(int epi);
+bool nt8o_eligible(const NTParams& p);                               // gemm_nt8o.hip: the wave-specialised overlap form
+int launch_gemm_nt8o(const NTParams& p, int nl, int dbg, hipStream_t stream);
 int launch_gemm_tn8(const bf16* A, int lda, const bf16* B, int ldb, int M, int N1, int N2, float* C, int ldc,
                     hipStream_t stream, float* colsum_a = nullptr, int* colsum_done = nullptr);

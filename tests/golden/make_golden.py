@@ -248,6 +248,90 @@ def gen_vae():
     print('vae_decode.npz written; image std', img.std().item(), 'absmax', img.abs().max().item())
 
 
+class _InjectedDraws:
+    """Feeds the reference's OWN code (train_utils/loss.py:35,39, models/maskdit.py:102) prescribed random draws: while
+    active, `torch.randn` / `torch.randn_like` / `torch.rand` hand out the queued tensors in call order (shape-checked)
+    instead of drawing.  The arithmetic that consumes them is untouched reference code."""
+
+    def __init__(self, *tensors):
+        self.q = list(tensors)
+
+    def _pop(self, shape):
+        t = self.q.pop(0)
+        assert tuple(t.shape) == tuple(shape), (tuple(t.shape), tuple(shape))
+        return t.clone()
+
+    def __enter__(self):
+        self.saved = (torch.randn, torch.randn_like, torch.rand)
+        torch.randn = lambda *size, **kw: self._pop(size[0] if len(size) == 1 and not isinstance(size[0], int) else size)
+        torch.randn_like = lambda x, **kw: self._pop(x.shape)
+        torch.rand = lambda *size, **kw: self._pop(size[0] if len(size) == 1 and not isinstance(size[0], int) else size)
+        return self
+
+    def __exit__(self, *a):
+        torch.randn, torch.randn_like, torch.rand = self.saved
+        assert not self.q, 'the reference consumed fewer draws than were queued'
+
+
+def gen_bs1024_grads(tag='xl2_bs1024_grads', seed=9, draw_seed=18, B=1024, S=16):
+    """BASELINE configs[1] AT ITS OWN SIZE, the oracle end of the chain: the REFERENCE (not the oracle)
+    runs train.py:216-220 -- `loss = loss_fn(net, images, labels, mask_ratio, mae_loss_coef); loss.mean().backward()` --
+    over the 1024-sample batch of tests/test_40_full_batch_gpu.py::_bs1024_inputs(18) as 64 slices of 16 samples
+    (gradients accumulate in `.grad`; the mean over 1024 is linear in the slices), with that test's draws injected into
+    the reference's own `torch.randn` / `randn_like` / `rand` calls.  Stored: all 1024 per-sample losses; for EVERY
+    parameter (sum, |sum|, L2) + 64 sampled entries (the `checks()` format); for the 16 named tensors of the test 4096
+    sampled entries more, so that a relative L2 error can be estimated without the 2.7 GB of gradients.
+    ~25 min on the build container's 8 cores."""
+    import time
+    cfg = O.make_cfg('DiT-XL/2', img_resolution=32)
+    P = O.init_params(cfg, seed=seed, dezero=True)
+    net = build_ref('DiT-XL/2', 32, P)
+    net.train()
+    wrapped = Wrap(net)
+    T = 256
+    g = torch.Generator().manual_seed(draw_seed)   # == _bs1024_inputs(draw_seed), statement for statement
+    images = 0.5 * torch.randn(B, 4, 32, 32, generator=g)
+    cls = torch.randint(0, 1000, (B,), generator=g)
+    labels = torch.zeros(B, 1000)
+    labels[torch.arange(B), cls] = 1
+    labels *= (torch.rand(B, 1, generator=g) >= 0.1).float()
+    rnd, noise = torch.randn(B, 1, 1, 1, generator=g), torch.randn(B, 4, 32, 32, generator=g)
+    mnoise = torch.rand(B, T, generator=g)
+    loss_fn = Losses['edm']()
+    losses = []
+    t0 = time.time()
+    for lo in range(0, B, S):
+        sl = slice(lo, lo + S)
+        with _InjectedDraws(rnd[sl], noise[sl], mnoise[sl]):
+            loss = loss_fn(net=wrapped, images=images[sl], labels=labels[sl], mask_ratio=0.5, mae_loss_coef=0.1)
+        (loss.sum() / B).backward()
+        losses.append(loss.detach())
+        print(f'  slice {lo // S + 1}/{B // S}  {time.time() - t0:.0f} s', flush=True)
+    names = [k for k in P if k not in O.NON_TRAINABLE]
+    sd = dict(net.named_parameters())
+    gc = [checks(sd[k].grad if sd[k].grad is not None else torch.zeros_like(sd[k])) for k in names]
+    named = [str(k) for k in BS1024_NAMED]
+    big = []
+    for k in named:
+        t64 = sd[k].grad.detach().double().flatten()
+        big.append(t64[sample_idx(t64.numel(), k=4096)].numpy())
+    np.savez_compressed(os.path.join(HERE, f'{tag}.npz'), seed=np.int64(seed), draw_seed=np.int64(draw_seed), B=np.int64(B),
+                        loss=torch.cat(losses).numpy(), param_names=np.array(names),
+                        grad_sums=np.stack([c[0] for c in gc]), grad_samples=np.stack([c[1] for c in gc]),
+                        named=np.array(named), named_samples=np.stack(big))
+    print(f'{tag}.npz written; loss mean {torch.cat(losses).mean().item():.6f}; {time.time() - t0:.0f} s')
+
+
+# one gradient per GEMM site of a block + the tensors with their own backward kernels (the list of
+# tests/test_40_full_batch_gpu.py::_NAMED_GRADS; the test asserts the two are equal)
+BS1024_NAMED = ['model.blocks.0.attn.qkv.weight', 'model.blocks.13.attn.qkv.bias', 'model.blocks.13.attn.proj.weight',
+                'model.blocks.27.mlp.fc1.weight', 'model.blocks.27.mlp.fc1.bias', 'model.blocks.5.mlp.fc2.weight',
+                'model.blocks.5.adaLN_modulation.1.weight', 'model.blocks.20.adaLN_modulation.1.bias',
+                'model.decoder_blocks.0.attn.qkv.weight', 'model.decoder_blocks.7.mlp.fc2.weight',
+                'model.decoder_layer.linear.weight', 'model.mask_token', 'model.x_embedder.proj.weight',
+                'model.final_layer.linear.weight', 'model.t_embedder.mlp.0.weight', 'model.y_embedder.embedding_table.weight']
+
+
 JOBS = {
     'vae': gen_vae,
     'param_order': gen_param_order,
@@ -265,9 +349,12 @@ JOBS = {
     'xl2_512_train': lambda: gen_train('xl2_512_train', 'DiT-XL/2', 64, 1, seed=8, with_grads=True),
     # configs[4]: XL/2, 50 Heun steps, cfg 1.5, the reference's fp32 network (sample.py:30-66)
     'xl2_sampler': lambda: gen_sampler('xl2_sampler', 'DiT-XL/2', 32, [0, 1], 50, 1.5, seed=7, nocfg=False),
+    # round 5: configs[1] at its own size -- the reference over the 64 slices of the batch-1024 test (NOT part of the no-argument run: ~25 min)
+    'xl2_bs1024_grads': gen_bs1024_grads,
 }
+SLOW_JOBS = {'xl2_bs1024_grads'}
 
 if __name__ == '__main__':
     # python tests/golden/make_golden.py [job ...]   (no arguments: every fixture)
-    for job in (sys.argv[1:] or list(JOBS)):
+    for job in (sys.argv[1:] or [j for j in JOBS if j not in SLOW_JOBS]):
         JOBS[job]()

@@ -554,6 +554,56 @@ def test_gemm_pipelines_poisoned_lds_stress(M, N, K, cus):
     assert worst <= 2e-5
 
 
+@pytest.mark.parametrize('M,N,K,epi,Lr,cus', [(1024, 256, 256, 'GATE_RES', 128, 0),      # 4 K-tiles: the shortest walk the ring supports
+                                               (2048, 384, 512, 'GATE_RES', 64, 5),       # 24 tiles on 5 workgroups (uneven), a gate row per 64-row half
+                                               (4096, 1152, 1152, 'GATE_RES', 128, 24),   # the XL/2 proj shape, 6 tiles per workgroup
+                                               (2048, 512, 256, 'GELU', 128, 3), (2304, 1152, 4608, 'GELU', 128, 0),
+                                               (1536, 384, 320, 'BF16', 128, 4), (8192, 3456, 1152, 'BF16', 128, 0)])
+def test_gemm_nt8o_wave_specialised_bit_identical(M, N, K, epi, Lr, cus):
+    """csrc/gemm_nt8o.hip (the epilogue-under-the-K-loop form with MMA / loader / epilogue WAVES that
+    synchronise through LDS counters) against the product gemm_nt8 on the same inputs: every output BIT-identical, with two
+    and with three loader waves, every launch behind mdt_lds_poison (a counter or ring slot read before it is written would
+    surface as NaN / stale operands) and operands alternately warm / evicted; the bounded-spin guard must never fire
+    (mdt_nt8o_report).  Measured slower than the product kernel (profiles/r5_nt8o_*.txt), so it is an A/B form behind
+    mdt_set_tuning("nt8_overlap") -- this test keeps it honest."""
+    import ctypes as C
+    torch.manual_seed(31)
+    A = bf(torch.randn(M, K, device=DEV) * 0.5)
+    W = bf(torch.randn(N, K, device=DEV) * 0.05)
+    b = torch.randn(N, device=DEV) * 0.1
+    kw = dict(bias=b, epi=getattr(ops, 'EPI_' + epi))
+    if epi == 'GATE_RES':
+        kw.update(res=torch.randn(M, N, device=DEV), gate=torch.randn(M // Lr, N, device=DEV), gate_ld=N, rows_per_sample=Lr)
+    lib = _lib.lib()
+    flush = torch.empty(1 << 26, device=DEV, dtype=torch.float32)
+
+    def run():
+        out, out2, outf = ops.gemm_nt(A, W, **kw)
+        return [t for t in (out, out2, outf) if t is not None]
+    code = C.c_uint32(0)
+    try:
+        lib.mdt_set_tuning(b'nt8_max_cus', cus)
+        lib.mdt_set_tuning(b'gemm_nt_variant', 2)
+        ref = run()
+        assert lib.mdt_nt8o_report(C.byref(code), None, 1) == 0
+        for ov in (3, 7):  # 2 loader + 2 epilogue waves / 3 + 1 (the plain class always runs 4 + 0)
+            assert lib.mdt_set_tuning(b'nt8_overlap', ov) == 0
+            for rep in range(12):
+                if rep & 1:
+                    flush.fill_(float(rep))
+                _poison_lds()
+                got = run()
+                for r, g in zip(ref, got):
+                    assert r.dtype == g.dtype and torch.equal(r.view(torch.int16 if r.dtype == torch.bfloat16 else torch.int32),
+                                                               g.view(torch.int16 if g.dtype == torch.bfloat16 else torch.int32)), \
+                        f'gemm_nt8o {epi} {M}x{N}x{K} overlap={ov} launch {rep}: output differs from gemm_nt8'
+            assert lib.mdt_nt8o_report(C.byref(code), None, 1) == 0
+            assert code.value == 0, f'a wave of gemm_nt8o gave up a bounded spin (code {code.value})'
+    finally:
+        for key in (b'nt8_overlap', b'nt8_max_cus', b'gemm_nt_variant'):
+            lib.mdt_set_tuning(key, 0)
+
+
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('B_,L,D', [(3, 128, 1152), (2, 64, 512), (5, 16, 384), (2, 32, 256), (2, 32, 768), (3, 16, 1024)])  # 1..5 quads per lane
 def test_ln_modulate_fwd_bwd(B_, L, D):

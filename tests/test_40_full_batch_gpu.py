@@ -139,6 +139,59 @@ def test_full_batch_backward_is_linear_in_slices_xl2_bs1024():
           f'peak allocated {peak / 2**30:.1f} GiB = {peak / total:.1%} of the device')
 
 
+def test_full_batch_backward_vs_reference_fixture_xl2_bs1024(golden_dir):
+    """BASELINE configs[1] AT ITS OWN SIZE against the REFERENCE ITSELF (train.py:216-220): the one-pass
+    batch-1024 step of the HIP path -- the persistent multi-tile GEMM walks, gemm_tn8 at 131 072 rows, 16 384-item
+    attention launches, exactly what bench.py times -- compared with tests/golden/xl2_bs1024_grads.npz, which
+    make_golden.py::gen_bs1024_grads wrote by running the reference's own EDMLoss / EDMPrecond / MaskDiT over the 64
+    16-sample slices of the same batch with the same draws injected (fp32, CPU, build container):
+      * all 1024 per-sample losses (1e-3 relative);
+      * EVERY parameter gradient's L2 norm against the reference's (1e-2) -- 376 tensors;
+      * for the 16 named tensors (one per GEMM site + the tensors with their own backward kernels) a relative L2 error over
+        4096 sampled entries (1e-2; sampling error of the estimate ~ 2 %), and for every tensor over its 64 sampled entries
+        (3e-2: 64 samples estimate the norm ratio to ~ 10 %)."""
+    from tests.golden.make_golden_idx import sample_idx
+    g = np.load(os.path.join(golden_dir, 'xl2_bs1024_grads.npz'))
+    assert [str(k) for k in g['named']] == _NAMED_GRADS
+    cfg, P, net = _build('DiT-XL/2', 32, int(g['seed']))
+    B, T = int(g['B']), 256
+    images, labels, rnd, noise, mnoise = _bs1024_inputs(int(g['draw_seed']))
+    md = M.get_mask(B, T, 0.5, DEV, noise=mnoise.to(DEV))
+    net.zero_grad(set_to_none=True)
+    l = M.Losses['edm']().with_draws(net, images.to(DEV), labels.to(DEV), rnd.to(DEV), noise.to(DEV), md, 0.1)
+    l.mean().backward()
+    ref_loss = torch.from_numpy(g['loss'])
+    rl = ((l.detach().cpu() - ref_loss).abs() / ref_loss.abs()).max().item()
+    assert rl <= TOL_LOSS, f'per-sample loss vs the reference: {rl:.3e}'
+    params = dict(net.named_parameters())
+    names = [str(n) for n in g['param_names']]
+    assert set(names) == set(k for k, p in params.items() if p.requires_grad)
+    bad, worst_norm, worst_s64 = [], (0.0, ''), (0.0, '')
+    for i, k in enumerate(names):
+        got = params[k].grad.detach().double().flatten()
+        ref_norm = float(g['grad_sums'][i][2])
+        en = abs(got.norm().item() - ref_norm) / (ref_norm + 1e-30)
+        ref64 = torch.from_numpy(g['grad_samples'][i])
+        got64 = got[torch.from_numpy(sample_idx(got.numel())).to(got.device)].cpu()
+        es = (got64 - ref64).norm().item() / (ref64.norm().item() + 1e-30)
+        worst_norm, worst_s64 = max(worst_norm, (en, k)), max(worst_s64, (es, k))
+        if en > TOL_GRAD or es > 3e-2:
+            bad.append(f'  {k}: norm err {en:.3e}, 64-sample rel L2 {es:.3e} (|g_ref| {ref_norm:.3e})')
+    table = []
+    for j, k in enumerate(_NAMED_GRADS):
+        got = params[k].grad.detach().double().flatten()
+        ref = torch.from_numpy(g['named_samples'][j])
+        gs = got[torch.from_numpy(sample_idx(got.numel(), k=4096)).to(got.device)].cpu()
+        e = (gs - ref).norm().item() / (ref.norm().item() + 1e-30)
+        table.append((e, k))
+        if e > TOL_GRAD:
+            bad.append(f'  {k}: 4096-sample rel L2 {e:.3e}')
+    print(f'XL/2 bs1024 vs the REFERENCE fixture: loss rel err {rl:.3e}; {len(names)} gradient norms, worst {worst_norm[0]:.3e} at '
+          f'{worst_norm[1]}; worst 64-sample rel L2 {worst_s64[0]:.3e} at {worst_s64[1]}; named tensors (4096 samples): '
+          + ', '.join(f'{k.split("model.")[-1]} {e:.2e}' for e, k in sorted(table, reverse=True)[:4]) + ' ...')
+    assert not bad, f'{len(bad)} gradient checks against the reference fixture failed:\n' + '\n'.join(bad[:40])
+
+
 @pytest.mark.skipif(os.environ.get('MASKDIT_SLOW') != '1', reason='~6 min of CPU oracle work: set MASKDIT_SLOW=1')
 def test_full_batch_backward_vs_oracle_slices_xl2_bs1024():
     """The same full-size step against the fp32 CPU ORACLE: the mean of the oracle's gradients over the 64 16-sample

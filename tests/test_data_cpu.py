@@ -3,6 +3,7 @@
 split, partial-batch drop, shuffle buffer = a permutation, and the prefetcher's ordering / error propagation.  CPU only."""
 import os
 import pickle
+import sys
 import tarfile
 
 import numpy as np
@@ -91,3 +92,87 @@ def test_lmdb_reader_says_what_is_missing(tmp_path):
     except ImportError:
         with pytest.raises(ImportError, match='lmdb'):
             D.LmdbLatents(str(tmp_path), 8, 32)
+
+
+def _lmdb_standin(monkeypatch):
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_standins')
+    monkeypatch.syspath_prepend(here)
+    sys.modules.pop('lmdb', None)
+    import lmdb
+    assert hasattr(lmdb, 'write_db'), 'the real lmdb is installed: this test drives the dict-backed stand-in'
+    return lmdb
+
+
+def _write_latent_db(lmdb, root, n, R, seed=3):
+    """Records in the reference's layout (train_utils/datasets.py:261-277): `z-{i}` = float32 bytes of the [2 C, R, R]
+    moments, `y-{i}` = the class as text, `length` = the record count as text."""
+    rs = np.random.RandomState(seed)
+    z = rs.randn(n, 8, R, R).astype(np.float32)
+    y = rs.randint(0, 1000, size=n)
+    tab = {b'length': str(n).encode('utf-8')}
+    for i in range(n):
+        tab[f'z-{i}'.encode('utf-8')] = z[i].tobytes()
+        tab[f'y-{i}'.encode('utf-8')] = str(int(y[i])).encode('utf-8')
+    lmdb.write_db(os.path.join(root, 'train'), tab)
+    return z, y
+
+
+def test_lmdb_reader_on_the_reference_record_layout(tmp_path, monkeypatch):
+    """maskdit_amd.data.LmdbLatents (the loader the shipped 256^2 config uses: train_utils/datasets.py:240-304 behind
+    train.py:166-176) EXECUTED against a dict-backed stand-in `lmdb` (the class had never run a line):
+    record decoding ([8, R, R] float32 moments + integer class), rank-strided disjoint shards whose union is one
+    permutation of the data set, a different order every epoch, whole batches only, determinism per seed -- and, where
+    /root/reference exists (build container), the REFERENCE's own ImageNetLatentDataset reading the same records
+    through the same stand-in returns identical (z, y) for every index."""
+    lmdb = _lmdb_standin(monkeypatch)
+    n, R, B, W = 53, 8, 4, 2
+    z, y = _write_latent_db(lmdb, str(tmp_path), n, R)
+    shards = [list(D.LmdbLatents(str(tmp_path), B, R, rank=r, world=W, seed=7, epochs=2)) for r in range(W)]
+    seen_epochs = [[], []]
+    for r in range(W):
+        share = len(range(r, n, W))
+        assert len(shards[r]) == 2 * (share // B), (r, len(shards[r]))
+        for k, (xs, ys) in enumerate(shards[r]):
+            assert xs.shape == (B, 8, R, R) and xs.dtype == np.float32 and ys.shape == (B,) and ys.dtype == np.int64
+            ep = k // (share // B)
+            for x1, y1 in zip(xs, ys):
+                hit = np.flatnonzero((z.reshape(n, -1) == x1.reshape(1, -1)).all(1))
+                assert len(hit) == 1 and int(y[hit[0]]) == int(y1)  # the record it claims to be, label attached to ITS latent
+                seen_epochs[ep].append((r, int(hit[0])))
+    for ep in range(2):
+        idx = [i for _, i in seen_epochs[ep]]
+        assert len(idx) == len(set(idx)), 'a record was served twice within one epoch (ranks must be disjoint)'
+    order0 = [i for r, i in seen_epochs[0] if r == 0]
+    order1 = [i for r, i in seen_epochs[1] if r == 0]
+    assert order0 != order1, 'the epoch reshuffle did not change the order'
+    again = list(D.LmdbLatents(str(tmp_path), B, R, rank=0, world=W, seed=7, epochs=2))
+    assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(again, shards[0]))
+    other = list(D.LmdbLatents(str(tmp_path), B, R, rank=0, world=W, seed=8, epochs=1))
+    assert not all(np.array_equal(a[1], b[1]) for a, b in zip(other, shards[0]))
+    # the prefetcher path train.py uses: device tensors out (CPU degradation), same content
+    pf = D.LatentPrefetcher(D.LmdbLatents(str(tmp_path), B, R, seed=7, epochs=1), 'cpu')
+    direct = list(D.LmdbLatents(str(tmp_path), B, R, seed=7, epochs=1))
+    got = [(m.clone(), l.clone()) for m, l in pf]
+    assert len(got) == n // B and all(np.array_equal(g[0].numpy(), d[0]) and np.array_equal(g[1].numpy(), d[1]) for g, d in zip(got, direct))
+    # a missing database is the stand-in's (= lmdb's) error, not a silent empty loader
+    with pytest.raises(Exception):
+        D.LmdbLatents(str(tmp_path / 'nowhere'), B, R)
+    ref_root = os.environ.get('MASKDIT_REFERENCE', '/root/reference')
+    if os.path.isdir(ref_root):
+        import types
+        tv = types.ModuleType('torchvision')
+        tvd = types.ModuleType('torchvision.datasets')
+        tvd.ImageFolder = tvd.VisionDataset = object
+        tv.datasets = tvd
+        monkeypatch.setitem(sys.modules, 'torchvision', tv)
+        monkeypatch.setitem(sys.modules, 'torchvision.datasets', tvd)
+        monkeypatch.syspath_prepend(ref_root)
+        for k in [k for k in sys.modules if k == 'train_utils' or k.startswith('train_utils.')]:
+            monkeypatch.delitem(sys.modules, k)
+        from train_utils.datasets import ImageNetLatentDataset  # the reference itself
+        ds = ImageNetLatentDataset(str(tmp_path), resolution=R, num_channels=4, split='train')
+        assert len(ds) == n
+        for i in range(n):
+            zr, yr = ds._load_raw_data(i)
+            assert np.array_equal(zr, z[i]) and yr == int(y[i])
+        ds.env.close()  # (the reference's own close() dereferences feat_env, which only the feature-conditioned path sets)

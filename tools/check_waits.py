@@ -30,6 +30,8 @@ scalar load in flight only lgkmcnt(0) is meaningful: SMEM returns out of order).
                 exactly the issue sequence the counts were derived from -- c_issue(p) LDS-DMAs, then
                 `vmcnt(wait_count(p))`, then the barrier -- and no other vector-memory operation
                 (tests/test_host_cpu.py::test_gemm_nt8_wait_counts proves that MODEL safe; this proves the ISA IS the model);
+  loader loop   gemm_nt8o (wave-specialised form): around the loaders' counted `vmcnt(NP / 2)` the loop issues nothing but
+                LDS-DMAs, NP / 2 before the wait and NP / 2 after it, none inside a nested loop;
   ring phases   gemm_tn8: every phase of the steady loop issues 3 unconditional LDS-DMAs (+ 1 under the `mover2` branch
                 for the 192-wide tile), waits with {3, 4} x (NSLOT - 2) in the two arms of the same branch, nothing else.
 
@@ -63,6 +65,7 @@ WATCH = {
     'gemm_nt8_c3.hip': [(r'gemm_nt8_kernel', 'nt8')],
     'gemm_nt8_c4.hip': [(r'gemm_nt8_kernel', 'nt8')],
     'gemm_nt8_conv.hip': [(r'gemm_nt8_kernel', 'nt8')],
+    'gemm_nt8o.hip': [(r'gemm_nt8o_kernel', 'nt8o')],
     'gemm_tn8.hip': [(r'gemm_tn8_kernel', 'tn8')],
     'norm.hip': [(r'ln_bwd_gate_split_kernel', 'generic'), (r'ln_modulate_(fwd|bwd)_kernel', 'generic')],
     'gemm.hip': [(r'gemm_(nt|tn)_kernel', 'generic')],
@@ -412,6 +415,8 @@ def rule_generic(kern, pretty, entry, rep, klass):
                 bad = sorted((ex[0] for st, ex in sts.items() if st[0] > 0), key=len)
                 if bad:
                     rep.err(pretty, f'line {ins.line}: MDT_CHK vm_empty: vector-memory operations may be in flight: "{bad[0]}"')
+            elif ins.marker == 'nt8o_loader_wait':
+                pass  # rule_nt8o
             else:
                 rep.err(pretty, f'line {ins.line}: unknown marker {ins.marker}')
         elif ins.kind == 'wait' and ins.vm and ins.hand:
@@ -593,6 +598,51 @@ def rule_tn8(kern, pretty, entry, rep):
 
 
 # ------------------------------------------------------------------------------------------ driver
+# ---- gemm_nt8o: the loader waves' counted wait -------------------------------------------------------------------------
+def rule_nt8o(kern, pretty, entry, rep):
+    """gemm_nt8o.hip: a loader wave publishes K-tile g - 1 behind `vmcnt(NP / 2)` issued after the first NP / 2 LDS-DMA
+    pieces of K-tile g.  That is right iff the wave's queue holds NOTHING but LDS-DMAs there and exactly NP / 2 of them
+    belong to K-tile g: in the smallest loop around every `; MDT_CHK nt8o_loader_wait` the only vector-memory
+    instructions must be LDS-DMAs, N of them in layout order before the wait and N after it (N = the wait's immediate),
+    and none may hide in a nested loop (the counter polls are LDS-only spins)."""
+    pos = {b.name: k for k, b in enumerate(kern.order)}
+    loops = kern.loops()
+    found = 0
+    for blk in kern.order:
+        for k, ins in enumerate(blk.ins):
+            if ins.kind != 'marker' or ins.marker != 'nt8o_loader_wait':
+                continue
+            found += 1
+            wait = next((i for i in blk.ins[k + 1:] if i.kind == 'wait'), None)
+            if wait is None or not wait.hand or not wait.vm:
+                rep.err(pretty, f'line {ins.line}: nt8o_loader_wait marker without a counted hand wait behind it')
+                continue
+            N = wait.vm
+            around = [r for r in loops if r[0] <= pos[blk.name] <= r[1]]
+            if not around:
+                rep.err(pretty, f'line {ins.line}: counted loader wait outside any loop')
+                continue
+            lo, hi = min(around, key=lambda r: r[1] - r[0])
+            inner = [r for r in loops if lo <= r[0] and r[1] <= hi and (r[0], r[1]) != (lo, hi)]
+            before = after = 0
+            for b in kern.order[lo:hi + 1]:
+                nested = any(r[0] <= pos[b.name] <= r[1] for r in inner)
+                for i in b.ins:
+                    if i.kind != 'vm':
+                        continue
+                    if i.vm != 'D' or nested:
+                        rep.err(pretty, f'line {i.line}: {i.op} ({"nested loop" if nested else "kind " + i.vm}) inside the loader loop of the '
+                                        f'counted wait at line {wait.line}: its queue must hold LDS-DMAs only')
+                    elif i.line < wait.line:
+                        before += 1
+                    else:
+                        after += 1
+            if before != N or after != N:
+                rep.err(pretty, f'line {wait.line}: loader loop issues {before} LDS-DMAs before and {after} after vmcnt({N}); both must be {N}')
+    if found == 0:
+        rep.err(pretty, 'no counted loader wait found (expected one per loader walk)')
+
+
 def check_file(src, defines, rep):
     asm = compile_asm(src, defines)
     kernels = parse_kernels(asm)
@@ -610,6 +660,8 @@ def check_file(src, defines, rep):
             rule_nt8(kern, f'{src}: {short}', entry, rep)
         elif klass == 'tn8':
             rule_tn8(kern, f'{src}: {short}', entry, rep)
+        elif klass == 'nt8o':
+            rule_nt8o(kern, f'{src}: {short}', entry, rep)
         done += 1
     return done
 
