@@ -23,6 +23,9 @@ typedef void* mdt_stream_t; /* hipStream_t */
 typedef uint16_t mdt_bf16;
 
 const char* mdt_last_error(void);
+/* ABI revision of this header: a binding must refuse a library whose mdt_version() differs (a changed signature would
+ * otherwise be called with the wrong argument list). */
+#define MDT_ABI_VERSION 3
 int mdt_version(void);
 /* Process-wide tuning knobs (benchmarking / A-B tests only; defaults are the product path).
  * "gemm_nt_variant": 0 = auto, 1 = force the 128x128-tile kernel, 2 = force the 256-row

@@ -96,6 +96,7 @@ _PLAIN = {
     'mdt_nt8o_report': [C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), i32],
 }
 EXPORTED = sorted(list(_PROTOS) + list(_PLAIN) + ['mdt_last_error', 'mdt_version'])
+ABI_VERSION = 3  # == MDT_ABI_VERSION of include/maskdit_hip.h (tests/test_capi_cpu.py compares the two)
 
 
 class MaskDiTLibError(RuntimeError):
@@ -141,6 +142,15 @@ def lib():
             f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
             f'(or `make -C {CSRC}`).  maskdit_amd has no non-HIP fallback.')
     L = C.CDLL(LIB_PATH)
+    missing = [n for n in EXPORTED if not hasattr(L, n)]
+    if missing:
+        raise MaskDiTLibError(f'{LIB_PATH} does not export {missing}: it was built from other sources than this package '
+                              f'(rebuild with `make -C {CSRC}`, or unset MASKDIT_HIP_LIB)')
+    L.mdt_version.restype = i32
+    L.mdt_version.argtypes = []
+    if L.mdt_version() != ABI_VERSION:
+        raise MaskDiTLibError(f'{LIB_PATH} has ABI revision {L.mdt_version()}, this package binds revision {ABI_VERSION} '
+                              f'(include/maskdit_hip.h MDT_ABI_VERSION): argument lists differ -- rebuild with `make -C {CSRC}`')
     for name, argt in _PROTOS.items():
         fn = getattr(L, name)
         fn.argtypes = argt + [vp]
@@ -157,7 +167,7 @@ def lib():
     for item in filter(None, os.environ.get('MDT_TUNE', '').split(',')):
         k, _, v = item.partition('=')
         if L.mdt_set_tuning(k.strip().encode(), int(v)) != 0:
-            raise MaskDiTLibError(f'MDT_TUNE: unknown knob {k!r}')
+            raise MaskDiTLibError(f'MDT_TUNE: {k.strip()}={v} refused by {LIB_PATH}: {L.mdt_last_error().decode()}')
     _lib = L
     return L
 

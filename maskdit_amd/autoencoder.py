@@ -14,7 +14,10 @@ GEMM (`mdt_conv3x3_nhwc`, round 3: the MFMA kernel gathers the nine taps, the ze
 from the NHWC activation -- rounds 1-2 materialised an im2col matrix of 9x the activation bytes), the 1x1 convolutions and
 conv_in (4 channels) are `mdt_gemm_nt` on the activation / a small im2col matrix; the mid-block attention
 (1024 tokens, one head of 512 channels) is three GEMMs per image around `mdt_softmax_rows`.  No torch arithmetic, no
-CPU fallback.  ddconfig is the reference's (ch 128, ch_mult (1, 2, 4, 4), 2 res blocks, no attention resolutions,
+CPU fallback.  Supported latent sides: 16, 32, 48, 64 (decode() raises for others).  Determinism: with the fused
+convolution epilogue (default) the next GroupNorm's statistics are accumulated with fp32 atomics across waves, so two decodes of
+the same latents can differ in the last bits; MDT_VAE_FUSE=0 selects the separate mdt_gn_stats pass, which is run-to-run
+bitwise reproducible (use it where that matters, e.g. FID bookkeeping across runs).  ddconfig is the reference's (ch 128, ch_mult (1, 2, 4, 4), 2 res blocks, no attention resolutions,
 z_channels 4, 3 output channels)."""
 from __future__ import annotations
 
@@ -198,9 +201,11 @@ class FrozenAutoencoderKL(nn.Module):
         Ho = H << up
         M = B * Ho * Ho
         # the implicit-GEMM kernel's shape domain (mdt_conv3x3_nhwc): power-of-two image sides >= 8, whole 256-row tiles,
-        # 8-bit batch index, 32-bit source offsets; anything else (R = 24 / 40 / 48 latents, a batch of one or two at
-        # R = 8) takes the materialised-im2col GEMM below, which has no shape restrictions (the reference
-        # decoder is size-agnostic)
+        # 8-bit batch index, 32-bit source offsets; anything else inside decode()'s domain (R = 48 latents: 48, 96, 192, 384
+        # pixel sides; a batch whose pixel rows are not whole 256-row tiles) takes the materialised-im2col GEMM below, which has
+        # no shape restriction of its own.  decode() itself accepts R = 16, 32, 48, 64 only (the mid-block attention's T x T
+        # GEMMs need R * R % 128 == 0): R = 8 / 24 / 40 raise NotImplementedError there -- the reference decoder is
+        # size-agnostic, this one covers the sides the shipped configs (32, 64) and their neighbours use
         implicit_ok = (k == 3 and cin % 128 == 0 and H >= 8 and (H & (H - 1)) == 0 and M % 256 == 0 and B < 256
                        and Ho <= 2048 and B * H * H * cin * 2 + 256 < (1 << 32))
         if implicit_ok:

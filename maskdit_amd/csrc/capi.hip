@@ -68,7 +68,9 @@ extern "C" int mdt_set_tuning(const char* key, int value) {
   mdt_set_error("set_tuning: unknown key");
   return MDT_ERR_ARG;
 }
-extern "C" int mdt_version(void) { return 1; }
+// ABI revision: bumped whenever an exported signature or struct layout changes (3: mdt_conv3x3_nhwc grew res / gn_sums /
+// gn_groups and mdt_lds_poison appeared in round 4, mdt_nt8o_report in round 5); maskdit_amd/_lib.py refuses any other value
+extern "C" int mdt_version(void) { return MDT_ABI_VERSION; }
 
 // ---- LDS poison (test support; include/maskdit_hip.h) ---------------------------------------------------------------
 // Every CU's LDS is left holding NaN bit patterns (0x7fc07fc0 = a quiet NaN as fp32 and as two bf16), so that a kernel

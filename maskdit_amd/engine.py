@@ -323,11 +323,17 @@ class Engine:
             # allocator's idle blocks), and the least-recently-used plan of ANY live engine on this device is dropped
             # until it fits (5 % of the device stays free for the caller's own tensors) or nothing is left to drop.
             while len(self._plans) >= 8:
-                self._plans.pop(next(iter(self._plans)))
+                _drop_plan(self, next(iter(self._plans)))
             need = PassPlan.estimate_bytes(self.sp, B, masked, train, Lv)
-            while need + self.plan_headroom * _device_total(self.device) > _device_available(self.device):
+            # (a plan something else still refers to -- a pending backward, a captured sampler graph -- gives no memory back
+            # when its cache entry goes: after two evictions in a row that freed nothing the loop stops instead of emptying
+            # every engine's cache for no gain)
+            fruitless = 0
+            while need + self.plan_headroom * _device_total(self.device) > _device_available(self.device) and fruitless < 2:
+                before = _device_available(self.device)
                 if not _evict_lru_plan(self.device):
                     break
+                fruitless = fruitless + 1 if _device_available(self.device) <= before else 0
             while True:
                 try:
                     pl = PassPlan(self, B, masked, train, Lv)
@@ -344,7 +350,8 @@ class Engine:
         return pl
 
     def release_plans(self):
-        self._plans.clear()
+        for key in list(self._plans):
+            _drop_plan(self, key)
 
 
 _PLAN_CLOCK = 0
@@ -360,6 +367,14 @@ def _device_available(device) -> int:
     return free + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
 
 
+def _drop_plan(eng, key):
+    """THE way a plan leaves a cache: whoever replays its launch list (the sampler's captured graphs) is told."""
+    pl = eng._plans.pop(key)
+    for hook in pl.evict_hooks:
+        hook()
+    pl.evict_hooks = []
+
+
 def _evict_lru_plan(device) -> bool:
     """Drop the least-recently-used cached plan among ALL live engines on `device`; False when none is cached.  (A plan a
     pending backward still refers to stays alive through that reference -- only the cache entry goes.)"""
@@ -372,10 +387,7 @@ def _evict_lru_plan(device) -> bool:
                 best = (eng, key, pl)
     if best is None:
         return False
-    del best[0]._plans[best[1]]
-    for hook in best[2].evict_hooks:  # e.g. the sampler's captured graphs, which replay this plan's launch list
-        hook()
-    best[2].evict_hooks = []
+    _drop_plan(best[0], best[1])
     return True
 
 
@@ -452,7 +464,8 @@ class PassPlan:
         per_tok_enc = 40 * sp.D if train else 0      # bytes of saved activations per encoder token and block
         per_tok_dec = 40 * sp.Dd if train else 0
         live = 64 * max(sp.D, sp.Dd) * sp.T          # per-sample working set of one block (fwd-only plans)
-        return int(B * (sp.depth * per_tok_enc * L + sp.ddepth * per_tok_dec * sp.T + live) * 1.05)
+        io = 6 * 4 * sp.C * sp.R * sp.R              # yn / D / y / noise-sized fp32 images of the loss + precond algebra
+        return int(B * (sp.depth * per_tok_enc * L + sp.ddepth * per_tok_dec * sp.T + live + io) * 1.05)
 
     def set_valid(self, Lv: int):
         if _rup(Lv, 64) != self.L or not (1 <= Lv <= self.T):

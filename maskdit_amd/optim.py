@@ -129,6 +129,15 @@ class FusedAdam(torch.optim.Optimizer):
 
     def _step_mixed(self, group, hyp):
         """Some (not all) gradients of an arena-bound model are None: per-tensor kernels on the parameters that have one."""
+        if not getattr(self, '_warned_mixed', False):
+            self._warned_mixed = True
+            import warnings
+            frozen = sum(1 for p in self._trainable if not p.requires_grad)
+            warnings.warn(f'FusedAdam: {sum(1 for p in self._trainable if p.grad is None)} of {len(self._trainable)} arena parameters have no '
+                          f'gradient ({frozen} of them no longer require one): this step -- and every step like it -- runs one kernel per '
+                          'tensor (hundreds of launches, EMA and bf16 shadows refreshed by separate passes) instead of the single '
+                          'arena kernel.  Results are the same; if the set is frozen for good, build the optimizer from the '
+                          'parameters that still train.', RuntimeWarning, stacklevel=3)
         self._step_tensors(group, hyp)
 
     def _step_arena(self, hyp):

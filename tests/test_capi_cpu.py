@@ -27,7 +27,8 @@ def test_header_symbols_exported(built):
 
 
 def test_version_and_error_string(built):
-    assert built.mdt_version() >= 1
+    hdr = open(os.path.join(ROOT, 'include', 'maskdit_hip.h')).read()
+    assert built.mdt_version() == _lib.ABI_VERSION == int(re.search(r'#define MDT_ABI_VERSION (\d+)', hdr).group(1))
     assert isinstance(built.mdt_last_error(), bytes)
 
 

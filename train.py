@@ -60,8 +60,44 @@ def save_ckpt_atomic(obj, path):
     """Write `<path>.tmp`, then rename: a job killed in the middle of a save leaves the previous checkpoint as the newest
     complete one instead of a truncated `<step>.pt` that every auto-resume would then crash on."""
     tmp = path + '.tmp'
-    torch.save(obj, tmp)
+    with open(tmp, 'wb') as f:
+        torch.save(obj, f)
+        f.flush()
+        os.fsync(f.fileno())  # the DATA is on stable storage before the name appears (power loss, lagging network file systems)
     os.replace(tmp, path)
+    try:  # ... and so is the directory entry
+        fd = os.open(os.path.dirname(os.path.abspath(path)), os.O_RDONLY)
+        try:
+            os.fsync(fd)
+        finally:
+            os.close(fd)
+    except OSError:
+        pass  # (file systems that cannot fsync a directory)
+
+
+def remove_stale_tmp(ckpt_dir, log=print):
+    """`<step>.pt.tmp` files are what a killed save leaves behind: never a checkpoint, only disk space."""
+    if os.path.isdir(ckpt_dir):
+        for f in os.listdir(ckpt_dir):
+            if re.fullmatch(r'\d+\.pt\.tmp', f):
+                try:
+                    os.remove(os.path.join(ckpt_dir, f))
+                    log(f'removed the leftover of an interrupted save: {f}')
+                except OSError:
+                    pass
+
+
+def load_ckpt_with_retry(path, tries=5, wait_s=2.0):
+    """torch.load for the ranks that did not choose the checkpoint: on a lagging shared file system the file rank 0 has
+    just validated may not be complete from here yet -- retry a few times before giving up."""
+    import time
+    for k in range(tries):
+        try:
+            return torch.load(path, map_location='cpu', weights_only=False)
+        except Exception:  # noqa: BLE001
+            if k + 1 == tries:
+                raise
+            time.sleep(wait_s)
 
 
 def load_newest_valid_ckpt(ckpt_dir, log=print):
@@ -246,6 +282,7 @@ def _train_loop(args, state):
     # experiment; otherwise <results_dir>/<exp_name>, resuming from its newest checkpoint if there is one
     resumed = False
     preloaded = None
+    early_log = []  # messages of the resume scan: printed once the Logger tees into log.txt (they used to precede it)
     if args.ckpt_path and args.use_ckpt_path and os.path.basename(os.path.dirname(os.path.abspath(args.ckpt_path))) == 'checkpoints':
         exp_dir = os.path.dirname(os.path.dirname(os.path.abspath(args.ckpt_path)))
     else:
@@ -255,7 +292,8 @@ def _train_loop(args, state):
             # directory on its own can disagree on a lagging file system, and then resumes from different steps
             choice = [None]
             if rank == 0:
-                choice[0], preloaded = load_newest_valid_ckpt(os.path.join(exp_dir, 'checkpoints'))
+                remove_stale_tmp(os.path.join(exp_dir, 'checkpoints'), log=early_log.append)
+                choice[0], preloaded = load_newest_valid_ckpt(os.path.join(exp_dir, 'checkpoints'), log=early_log.append)
             if world > 1:
                 dist.broadcast_object_list(choice, src=0)
             args.ckpt_path = choice[0]
@@ -265,6 +303,8 @@ def _train_loop(args, state):
         os.makedirs(os.path.join(exp_dir, 'checkpoints'), exist_ok=True)
         logger = state['logger'] = Logger(os.path.join(exp_dir, 'log.txt'))
         print(f'Experiment directory created at {exp_dir}', flush=True)
+        for msg in early_log:
+            print(msg, flush=True)
         if resumed:
             print(f'resuming from the latest checkpoint {args.ckpt_path}', flush=True)
     # data parallelism first: the sharded optimizer (train.zero1) needs the wrapper's reducer
@@ -277,7 +317,9 @@ def _train_loop(args, state):
         opt = M.FusedAdam(net.parameters(), lr=tc.lr, adam_w_mode=True, weight_decay=0)
     step0 = 0
     if args.ckpt_path:  # train.py:147-162
-        ck = preloaded if preloaded is not None else torch.load(args.ckpt_path, map_location='cpu', weights_only=False)
+        if world > 1:
+            dist.barrier()  # rank 0 has read the whole file: the others start reading a file that is known to be complete
+        ck = preloaded if preloaded is not None else load_ckpt_with_retry(args.ckpt_path)
         preloaded = None
         net.load_state_dict(strip_compile_prefix(ck['model']), strict=args.use_strict_load)
         ema.load_state_dict(strip_compile_prefix(ck['ema']), strict=args.use_strict_load)
