@@ -16,6 +16,7 @@
 //   * backward = two kernels (dQ; dK+dV), each recomputing P from the saved log-sum-exp,
 //     no atomics.
 #include "common.h"
+#include <type_traits>
 #include "../../include/maskdit_hip.h"
 
 template <int HD>
@@ -560,12 +561,18 @@ template <int HD, int L> constexpr bool sp_split = SpCfg<HD>::SPLIT && L <= 256;
 #else
 template <int HD, int L> constexpr bool sp_split = false;
 #endif
+// hd 32 as UNPADDED, XOR-swizzled 64-byte rows (SpCfg::SWZ4's image; enumerated conflict-free by
+// tools/attn_lds_conflicts.py): measured slower for the L = 256 decoder kernels (round 4: an A/B build), but for
+// L = 1024 (round 5: the decoder at 512 x 512 latents, BASELINE configs[3]) it is what lets TWO whole tiles -- K and V, or Q
+// and dO -- of a (sample, head) stay resident: 2 x 64 KiB instead of 2 x 80 KiB of LDS.
+template <int HD, int L> constexpr bool sp_swz4 = SpCfg<HD>::SWZ4 || (HD == 32 && L >= 1024);
+template <int HD, int L> constexpr int sp_pitch = sp_swz4<HD, L> ? 64 : SpCfg<HD>::PITCH;
 
 // byte offset of 16-byte chunk c (0 .. CH-1) of `row` inside an L-row tile
 template <int HD, int L>
 __device__ __forceinline__ int sp_chunk_off(int row, int c) {
   if constexpr (sp_split<HD, L>) return c < 8 ? row * 128 + ((c ^ (row & 7)) << 4) : L * 128 + row * 16;
-  else if constexpr (SpCfg<HD>::SWZ4) return row * 64 + ((c ^ ((row >> 1) & 3)) << 4);  // (staging: any row)
+  else if constexpr (sp_swz4<HD, L>) return row * 64 + ((c ^ ((row >> 1) & 3)) << 4);  // (staging: any row)
   else return row * SpCfg<HD>::PITCH + c * 16;
 }
 
@@ -576,7 +583,7 @@ __device__ __forceinline__ bf16x8 sp_frag_rows(const char* tile, int row, int s,
 #pragma unroll
   for (int e = 0; e < 8; ++e) z[e] = (bf16)0.f;
   const int d0 = 32 * s + 8 * g;
-  if constexpr (SpCfg<HD>::SWZ4) {
+  if constexpr (sp_swz4<HD, L>) {
     // every call site reads row = (multiple of 16) + (lane & 15): the swizzle (row >> 1) & 3 is a LANE constant, so the
     // address stays [uniform base] + [one per-lane offset] (with the row in the XOR hipcc recomputed it per read)
     const int swz = ((int)(threadIdx.x & 15) >> 1) & 3;
@@ -595,7 +602,7 @@ __device__ __forceinline__ bf16x8 sp_frag_cols(const char* tile, int rbase, int 
     const int sub = (i16 & 1) << 3;
     const char* q = (fd < 4) ? tile + row * 128 + (((2 * fd + ((i16 & 3) >> 1)) ^ (row & 7)) << 4) + sub : tile + L * 128 + row * 16 + sub;
     return cat4(lds_tr_read(q), lds_tr_read(q + (fd < 4 ? 16 * 128 : 16 * 16)));
-  } else if constexpr (SpCfg<HD>::SWZ4) {
+  } else if constexpr (sp_swz4<HD, L>) {
     // chunk 2 fd + (piece >> 1) of the lane's row, XOR-ed with (row >> 1) & 3 = (2 g + (i16 >> 3)) & 3 for every row base that
     // is a multiple of 8 (all callers: multiples of 32); row + 16 has the same swizzle
     const int swz = (2 * g + (i16 >> 3)) & 3;  // a lane constant (rbase % 8 == 0)
@@ -655,7 +662,9 @@ __device__ __forceinline__ void sp_block_coords(int B, int H, int& b, int& h) {
   attn_block_coords(1, B, H, b, h, blk);
 }
 
-template <int HD, int KF>
+// PAD: the launch has padding keys (L_valid < L) -- a separate instantiation, so that the common no-padding kernel carries
+// neither the per-score select nor a branch inside its query loop
+template <int HD, int KF, bool PAD>
 __global__ __launch_bounds__(512) void attn_fwd_sp_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
                                                           float* __restrict__ lse, int H, float scale_log2e, int Lv) {
   using C = SpCfg<HD>;
@@ -708,21 +717,31 @@ __global__ __launch_bounds__(512) void attn_fwd_sp_kernel(const bf16* __restrict
 #pragma unroll
       for (int ks = 0; ks < C::KSTEPS; ++ks) s[f] = mfma16(sp_frag_rows<HD, L>(Ks, 16 * f + i16, ks, g), qf[qi][ks], s[f]);
     }
+    // Round 5: per score the vector ALU now does max, ONE fma (the softmax scale folded into the exp2 argument), the
+    // hardware exp2 and an add.  Rounds 2-4 multiplied by the scale, selected the padding mask on EVERY score and called
+    // exp2f, which hipcc expands with a denormal-range path (v_ldexp + 3 selects + 2 compares per call): ~ 12 instead of 4-5
+    // issue slots per score in a kernel that issues 16-44 MFMAs per 512-2048 scores.  The padding select (keys >= Lv: no
+    // probability mass) exists only in the PAD instantiation (chosen at launch: a run-time branch INSIDE the query loop
+    // kept hipcc from running query block i + 1's MFMAs under block i's softmax -- L 256 / hd 72 got 14 % slower -- and
+    // two copies of the loop in one kernel cost 30-60 registers).
+    if (PAD) {
+#pragma unroll
+      for (int f = 0; f < L / 16; ++f)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[f][r] = (16 * f + 4 * g + r < Lv) ? s[f][r] : -1e30f;
+    }
     float mx = -1e30f;
 #pragma unroll
     for (int f = 0; f < L / 16; ++f)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s[f][r] = (16 * f + 4 * g + r < Lv) ? s[f][r] * scale_log2e : -1e30f;  // padding keys: no probability mass
-        mx = fmaxf(mx, s[f][r]);
-      }
-    mx = group_max(mx);
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[f][r]);
+    mx = group_max(mx) * scale_log2e;  // (scale > 0: the max commutes with it)
     float psum = 0.f;
 #pragma unroll
     for (int f = 0; f < L / 16; ++f)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        s[f][r] = exp2f(s[f][r] - mx);
+        s[f][r] = fast_exp2(__builtin_fmaf(s[f][r], scale_log2e, -mx));
         psum += s[f][r];
       }
     const float l_tot = group_sum(psum);
@@ -742,6 +761,139 @@ __global__ __launch_bounds__(512) void attn_fwd_sp_kernel(const bf16* __restrict
     attn_pack_row<HD>(orw, o, inv);
     attn_store_row<HD>(orow, g, orw);
     if (g == 0) lse[((long)b * H + h) * L + q] = mx + log2f(l_tot);
+  }
+}
+
+// Forward for sequences whose K and V tiles fit LDS but whose score row does not fit registers (L = 1024 at hd 32: the
+// decoder at 512 x 512 latents, BASELINE configs[3]; 2 x 64 KiB with the swizzled 64-byte rows).  One 8-wave workgroup per
+// (sample, head): K and V are staged ONCE, then every wave walks its L / 8 queries in blocks of 2 x 16 with an online
+// softmax over 128-key steps -- no barrier, no global load and no staging inside the loop (the block-loop kernel
+// attn_fwd_kernel re-stages K / V synchronously once per 128-query block: 8 x per head at L = 1024, two barriers per 64
+// keys).  Each K / V fragment read from LDS feeds two MFMAs (the two query blocks).  What is left is the softmax's
+// vector-ALU work (hd 32: 8 MFMAs per 2048 scores), which the second wave of every SIMD overlaps with its own MFMAs.
+template <int HD, int KF>
+__global__ __launch_bounds__(512, 2) void attn_fwd_res_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ out,
+                                                               float* __restrict__ lse, int H, float scale_log2e, int Lv) {
+  using C = SpCfg<HD>;
+  constexpr int L = 128 * KF;
+  constexpr int TILE = L * sp_pitch<HD, L>;
+  constexpr int QF = 2;    // query blocks per pass
+  constexpr int KB = 128;  // keys per online-softmax step (8 score fragments per query block)
+  static_assert(C::KSTEPS * 32 >= HD && KF % QF == 0, "shape");
+  __shared__ __attribute__((aligned(16))) char smem[2 * TILE + 64];
+  char* Ks = smem;
+  char* Vs = smem + TILE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i16 = lane & 15, g = lane >> 4;
+  int b, h;
+  sp_block_coords(gridDim.y / H, H, b, h);
+  const int D = H * HD;
+  const long ld = 3L * D;
+  const bf16* base = qkv + (long)b * L * ld + h * HD;
+  {
+    SpRegs<HD, L> kreg, vreg;
+    sp_load_nb<HD, L>(kreg, base + D, ld, tid);
+    sp_load_nb<HD, L>(vreg, base + 2 * D, ld, tid);
+    sp_store<HD, L>(kreg, Ks, tid);
+    sp_store<HD, L>(vreg, Vs, tid);
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int qp = 0; qp < KF; qp += QF) {
+    bf16x8 qf[QF][C::KSTEPS];
+#pragma unroll
+    for (int qi = 0; qi < QF; ++qi) {
+      const bf16* qrow = base + (long)(wave * 16 * KF + 16 * (qp + qi) + i16) * ld;
+#pragma unroll
+      for (int s2 = 0; s2 < C::KSTEPS; ++s2) {
+        qf[qi][s2] = *(const bf16x8*)(qrow + min(32 * s2 + 8 * g, HD - 8));
+        const bool in = 32 * s2 + 8 * g < HD;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[qi][s2][e] = in ? qf[qi][s2][e] : (bf16)0.f;
+      }
+    }
+    f32x4 o[QF][C::NFRAG];
+    float m_run[QF], l_run[QF];
+#pragma unroll
+    for (int qi = 0; qi < QF; ++qi) {
+#pragma unroll
+      for (int f = 0; f < C::NFRAG; ++f) o[qi][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      m_run[qi] = -1e30f;
+      l_run[qi] = 0.f;
+    }
+#pragma unroll 1
+    for (int kb = 0; kb < L; kb += KB) {
+      // S^T fragments: rows = keys kb + 16 f + 4 g + r, col = query i16
+      f32x4 s[QF][KB / 16];
+#pragma unroll
+      for (int f = 0; f < KB / 16; ++f) {
+#pragma unroll
+        for (int qi = 0; qi < QF; ++qi) s[qi][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < C::KSTEPS; ++ks) {
+          const bf16x8 kfr = sp_frag_rows<HD, L>(Ks, kb + 16 * f + i16, ks, g);
+#pragma unroll
+          for (int qi = 0; qi < QF; ++qi) s[qi][f] = mfma16(kfr, qf[qi][ks], s[qi][f]);
+        }
+      }
+      bf16x8 pf[QF][KB / 32];
+#pragma unroll
+      for (int qi = 0; qi < QF; ++qi) {
+        // vector-ALU work per score: max, one fma (the softmax scale is folded into the exp2 argument), exp2, add --
+        // and the padding select (keys >= Lv: no probability mass) only in the steps that reach past Lv (wave-uniform)
+        if (kb + KB > Lv) {
+#pragma unroll
+          for (int f = 0; f < KB / 16; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s[qi][f][r] = (kb + 16 * f + 4 * g + r < Lv) ? s[qi][f][r] : -1e30f;
+        }
+        float mx = -1e30f;
+#pragma unroll
+        for (int f = 0; f < KB / 16; ++f)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qi][f][r]);
+        mx = group_max(mx);
+        const float m_new = fmaxf(m_run[qi], mx * scale_log2e);  // (scale > 0; a fully padded step leaves -1e30 * scale)
+        const float alpha = fast_exp2(m_run[qi] - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int f = 0; f < KB / 16; ++f)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = fast_exp2(__builtin_fmaf(s[qi][f][r], scale_log2e, -m_new));
+            s[qi][f][r] = pv;
+            psum += pv;
+          }
+        l_run[qi] = l_run[qi] * alpha + psum;
+        m_run[qi] = m_new;
+#pragma unroll
+        for (int f = 0; f < C::NFRAG; ++f)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[qi][f][r] *= alpha;
+#pragma unroll
+        for (int ks = 0; ks < KB / 32; ++ks) pf[qi][ks] = pack_pair(s[qi][2 * ks], s[qi][2 * ks + 1]);
+      }
+      // O^T += V^T P^T: contraction over the step's keys, 32 at a time
+#pragma unroll
+      for (int ks = 0; ks < KB / 32; ++ks)
+#pragma unroll
+        for (int f = 0; f < C::NFRAG; ++f) {
+          const bf16x8 vfr = sp_frag_cols<HD, L>(Vs, kb + 32 * ks, f, i16, g);
+#pragma unroll
+          for (int qi = 0; qi < QF; ++qi) o[qi][f] = mfma16(vfr, pf[qi][ks], o[qi][f]);
+        }
+    }
+#pragma unroll
+    for (int qi = 0; qi < QF; ++qi) {
+      const int q = wave * 16 * KF + 16 * (qp + qi) + i16;
+      const float l_tot = group_sum(l_run[qi]);
+      const float inv = 1.f / l_tot;
+      bf16* orow = out + ((long)b * L + q) * D + h * HD;
+      AttnRow<HD> orw;
+      attn_pack_row<HD>(orw, o[qi], inv);
+      attn_store_row<HD>(orow, g, orw);
+      if (g == 0) lse[((long)b * H + h) * L + q] = m_run[qi] + log2f(l_tot);
+    }
   }
 }
 
@@ -845,7 +997,7 @@ __global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __res
       }
       dl = group_sum(dl);
       if (g == 0) {
-        del_s[q] = dl;
+        del_s[q] = dl * scale;  // (LDS copy pre-multiplied: dS = P * fma(dP, scale, -delta * scale))
         delta[bh * L + q] = dl;
       }
     }
@@ -900,9 +1052,10 @@ __global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __res
           const f32x4 dl = *(const f32x4*)(del_s + qb + 16 * f + 4 * g);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pv = key_ok ? fast_exp2(s[r] * scale_log2e - ls[r]) : 0.f;
+            // (no per-score padding select: a padding KEY is this lane's accumulator COLUMN -- zeroed once, below)
+            const float pv = fast_exp2(__builtin_fmaf(s[r], scale_log2e, -ls[r]));
             pm[f][r] = pv;
-            ds[f][r] = pv * (dp[r] - dl[r]) * scale;
+            ds[f][r] = pv * __builtin_fmaf(dp[r], scale, -dl[r]);
           }
         }
 #pragma unroll
@@ -918,6 +1071,10 @@ __global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __res
       }
       bf16* drow = dqkv + ((long)b * L + k0 + i16) * ld + h * HD;
       AttnRow<HD> krw, vrw;
+      if (!key_ok) {  // padding key column: whatever its scores produced (possibly inf) must not reach dK / dV
+#pragma unroll
+        for (int f = 0; f < C::NFRAG; ++f) dk[f] = dv[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
       attn_pack_row<HD>(krw, dk);
       attn_pack_row<HD>(vrw, dv);
       if (!MDT_EXP(dbg & 1)) {
@@ -953,8 +1110,12 @@ __global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __res
           }
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float pv = (kb + 16 * f + 4 * g + r < Lv) ? fast_exp2(s[r] * scale_log2e - my_lse) : 0.f;
-            ds[f][r] = pv * (dp[r] - dl) * scale;
+            const float pv = fast_exp2(__builtin_fmaf(s[r], scale_log2e, -my_lse));
+            ds[f][r] = pv * __builtin_fmaf(dp[r], scale, -dl);  // dl = delta * scale
+          }
+          if (kb + 64 > Lv) {  // (wave-uniform: only key blocks that reach past Lv pay for the padding select)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ds[f][r] = (kb + 16 * f + 4 * g + r < Lv) ? ds[f][r] : 0.f;
           }
         }
 #pragma unroll
@@ -1022,9 +1183,10 @@ __device__ __forceinline__ void attn_bwd_item_math(const char* Qs, const char* K
         const f32x4 dl = *(const f32x4*)(del_s + qb + 16 * f + 4 * g);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = key_ok ? fast_exp2(s[r] * scale_log2e - ls[r]) : 0.f;
+          // (no per-score padding select: a padding KEY is this lane's accumulator COLUMN -- zeroed once, below)
+          const float pv = fast_exp2(__builtin_fmaf(s[r], scale_log2e, -ls[r]));
           pm[f][r] = pv;
-          ds[f][r] = pv * (dp[r] - dl[r]) * scale;
+          ds[f][r] = pv * __builtin_fmaf(dp[r], scale, -dl[r]);
         }
       }
 #pragma unroll
@@ -1039,6 +1201,10 @@ __device__ __forceinline__ void attn_bwd_item_math(const char* Qs, const char* K
       }
     }
     bf16* drow = dbase + (long)(k0 + i16) * ld;
+    if (!key_ok) {  // padding key column: whatever its scores produced (possibly inf) must not reach dK / dV
+#pragma unroll
+      for (int f = 0; f < C::NFRAG; ++f) dk[f] = dv[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     attn_pack_row<HD>(k_keep, dk);
     attn_pack_row<HD>(v_keep, dv);
     attn_store_row<HD>(drow + D, g, k_keep);
@@ -1070,8 +1236,12 @@ __device__ __forceinline__ void attn_bwd_item_math(const char* Qs, const char* K
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = (kb + 16 * f + 4 * g + r < Lv) ? fast_exp2(s[r] * scale_log2e - my_lse) : 0.f;
-          ds[f][r] = pv * (dp[r] - dl) * scale;
+          const float pv = fast_exp2(__builtin_fmaf(s[r], scale_log2e, -my_lse));
+          ds[f][r] = pv * __builtin_fmaf(dp[r], scale, -dl);  // dl = delta * scale
+        }
+        if (kb + 64 > Lv) {  // (wave-uniform: only key blocks that reach past Lv pay for the padding select)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ds[f][r] = (kb + 16 * f + 4 * g + r < Lv) ? ds[f][r] : 0.f;
         }
       }
 #pragma unroll
@@ -1225,7 +1395,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dma_kernel(const bf16* __rest
       }                                                                                                    \
       dl = group_sum(dl);                                                                                  \
       if (g == 0) {                                                                                        \
-        del_s[qrow] = dl;                                                                                  \
+        del_s[qrow] = dl * scale; /* pre-multiplied: dS = P * fma(dP, scale, -delta * scale) */             \
         delta[bh * L + qrow] = dl;                                                                         \
       }                                                                                                    \
     }                                                                                                      \
@@ -1283,7 +1453,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_q_res_kernel(const bf16* __re
                                                                  float scale, float scale_log2e, int Lv) {
   using C = SpCfg<HD>;
   constexpr int L = 128 * KF;
-  constexpr int TILE = L * C::PITCH;
+  constexpr int TILE = L * sp_pitch<HD, L>;
   __shared__ __attribute__((aligned(16))) char smem[2 * TILE + 64];
   char* Ks = smem;
   char* Vs = smem + TILE;
@@ -1331,6 +1501,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_q_res_kernel(const bf16* __re
     }
     dl = group_sum(dl);
     if (g == 0) delta[bh * L + q] = dl;
+    const float dl_s = dl * scale;
     f32x4 dq[C::NFRAG];
 #pragma unroll
     for (int f = 0; f < C::NFRAG; ++f) dq[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1345,10 +1516,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_q_res_kernel(const bf16* __re
           sv = mfma16(sp_frag_rows<HD, L>(Ks, kb + 16 * f + i16, ks, g), qf[ks], sv);
           dp = mfma16(sp_frag_rows<HD, L>(Vs, kb + 16 * f + i16, ks, g), dqo[ks], dp);
         }
+        // per score: fma + exp2 (P), fma + mul (dS = P (dP - delta) scale, the scale folded into the fma); the padding
+        // select (keys >= Lv) only in the key blocks that reach past Lv (wave-uniform)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = (kb + 16 * f + 4 * g + r < Lv) ? fast_exp2(sv[r] * scale_log2e - my_lse) : 0.f;
-          ds[f][r] = pv * (dp[r] - dl) * scale;
+          const float pv = fast_exp2(__builtin_fmaf(sv[r], scale_log2e, -my_lse));
+          ds[f][r] = pv * __builtin_fmaf(dp[r], scale, -dl_s);
+        }
+        if (kb + 64 > Lv) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ds[f][r] = (kb + 16 * f + 4 * g + r < Lv) ? ds[f][r] : 0.f;
         }
       }
 #pragma unroll
@@ -1372,7 +1549,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv_res_kernel(const bf16* __r
                                                                   float scale_log2e, int Lv) {
   using C = SpCfg<HD>;
   constexpr int L = 128 * KF;
-  constexpr int TILE = L * C::PITCH;
+  constexpr int TILE = L * sp_pitch<HD, L>;
   __shared__ __attribute__((aligned(16))) char smem[2 * TILE + 2 * L * 4 + 64];
   char* Qs = smem;
   char* dOs = smem + TILE;
@@ -1390,13 +1567,20 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv_res_kernel(const bf16* __r
     SpRegs<HD, L> qreg, doreg;
     sp_load_nb<HD, L>(qreg, base, ld, tid);
     sp_load_nb<HD, L>(doreg, dout + (long)b * L * D + h * HD, D, tid);
-    const float ls = lse[bh * L + (tid & (L - 1))], dd = delta[bh * L + (tid & (L - 1))];
+    float ls[(L + 511) / 512], dd[(L + 511) / 512];
+#pragma unroll
+    for (int k = 0; k < (L + 511) / 512; ++k) {
+      ls[k] = lse[bh * L + ((tid + 512 * k) & (L - 1))];
+      dd[k] = delta[bh * L + ((tid + 512 * k) & (L - 1))];
+    }
     sp_store<HD, L>(qreg, Qs, tid);
     sp_store<HD, L>(doreg, dOs, tid);
-    if (tid < L) {
-      lse_s[tid] = ls;
-      del_s[tid] = dd;
-    }
+#pragma unroll
+    for (int k = 0; k < (L + 511) / 512; ++k)
+      if (tid + 512 * k < L) {
+        lse_s[tid + 512 * k] = ls[k];
+        del_s[tid + 512 * k] = dd[k] * scale;
+      }
   }
   __syncthreads();
 #pragma unroll 1
@@ -1424,7 +1608,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv_res_kernel(const bf16* __r
       dk[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
       dv[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    const bool key_ok = (k0 + i16) < Lv;
+    const float key_pen = (k0 + i16) < Lv ? 0.f : 1e30f;
 #pragma unroll 1
     for (int qb = 0; qb < L; qb += 64) {
       f32x4 pm[4], ds[4];
@@ -1437,12 +1621,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv_res_kernel(const bf16* __r
           dp = mfma16(sp_frag_rows<HD, L>(dOs, qb + 16 * f + i16, ks, g), vf[ks], dp);
         }
         const f32x4 ls = *(const f32x4*)(lse_s + qb + 16 * f + 4 * g);
-        const f32x4 dl = *(const f32x4*)(del_s + qb + 16 * f + 4 * g);
+        const f32x4 dl = *(const f32x4*)(del_s + qb + 16 * f + 4 * g);  // delta * scale (pre-multiplied at staging)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = key_ok ? fast_exp2(sv[r] * scale_log2e - ls[r]) : 0.f;
+          // a padding KEY (this lane's column, >= Lv) costs nothing per score: its penalty makes P = exp2(-huge) = 0
+          const float pv = fast_exp2(__builtin_fmaf(sv[r], scale_log2e, -ls[r]) - key_pen);
           pm[f][r] = pv;
-          ds[f][r] = pv * (dp[r] - dl[r]) * scale;
+          ds[f][r] = pv * __builtin_fmaf(dp[r], scale, -dl[r]);
         }
       }
 #pragma unroll
@@ -1490,11 +1675,18 @@ extern "C" int mdt_attn_fwd(const mdt_bf16* qkv, mdt_bf16* out, float* lse, int 
   // short sequences: one workgroup per (sample, head), single pass ("attn_sp" = 1 forces the block-loop kernels: A/B)
   if ((L == 128 || L == 256) && mdt_get_tuning_int(MDT_TUNE_ATTN_SP) != 1) {
     dim3 grid(1, B * H);
-    if (L == 128) {
-      ATTN_DISPATCH(hd, hipLaunchKernelGGL((attn_fwd_sp_kernel<HDc, 1>), grid, dim3(512), 0, (hipStream_t)stream,
+    const bool pad = L_valid < L;
+    if (L == 128 && !pad) {
+      ATTN_DISPATCH(hd, hipLaunchKernelGGL((attn_fwd_sp_kernel<HDc, 1, false>), grid, dim3(512), 0, (hipStream_t)stream,
+                                           (const bf16*)qkv, (bf16*)out, lse, H, sl, L_valid));
+    } else if (L == 128) {
+      ATTN_DISPATCH(hd, hipLaunchKernelGGL((attn_fwd_sp_kernel<HDc, 1, true>), grid, dim3(512), 0, (hipStream_t)stream,
+                                           (const bf16*)qkv, (bf16*)out, lse, H, sl, L_valid));
+    } else if (!pad) {
+      ATTN_DISPATCH(hd, hipLaunchKernelGGL((attn_fwd_sp_kernel<HDc, 2, false>), grid, dim3(512), 0, (hipStream_t)stream,
                                            (const bf16*)qkv, (bf16*)out, lse, H, sl, L_valid));
     } else {
-      ATTN_DISPATCH(hd, hipLaunchKernelGGL((attn_fwd_sp_kernel<HDc, 2>), grid, dim3(512), 0, (hipStream_t)stream,
+      ATTN_DISPATCH(hd, hipLaunchKernelGGL((attn_fwd_sp_kernel<HDc, 2, true>), grid, dim3(512), 0, (hipStream_t)stream,
                                            (const bf16*)qkv, (bf16*)out, lse, H, sl, L_valid));
     }
     return mdt_check_launch("attn_fwd_sp");
@@ -1504,9 +1696,19 @@ extern "C" int mdt_attn_fwd(const mdt_bf16* qkv, mdt_bf16* out, float* lse, int 
   // kernel applies with four query blocks per wave; every K / V byte is then read once per head instead of once per
   // 64-query block.
   if (L == 512 && hd == 72 && mdt_get_tuning_int(MDT_TUNE_ATTN_SP) != 1) {
-    hipLaunchKernelGGL((attn_fwd_sp_kernel<72, 4>), dim3(1, B * H), dim3(512), 0, (hipStream_t)stream, (const bf16*)qkv,
-                       (bf16*)out, lse, H, sl, L_valid);
+    if (L_valid < L)
+      hipLaunchKernelGGL((attn_fwd_sp_kernel<72, 4, true>), dim3(1, B * H), dim3(512), 0, (hipStream_t)stream, (const bf16*)qkv,
+                         (bf16*)out, lse, H, sl, L_valid);
+    else
+      hipLaunchKernelGGL((attn_fwd_sp_kernel<72, 4, false>), dim3(1, B * H), dim3(512), 0, (hipStream_t)stream, (const bf16*)qkv,
+                         (bf16*)out, lse, H, sl, L_valid);
     return mdt_check_launch("attn_fwd_sp");
+  }
+  // L = 1024 at hd 32 (the decoder at 512 x 512 latents): K and V resident as swizzled 64-byte rows, online softmax
+  if (L == 1024 && hd == 32 && mdt_get_tuning_int(MDT_TUNE_ATTN_SP) != 1) {
+    hipLaunchKernelGGL((attn_fwd_res_kernel<32, 8>), dim3(1, B * H), dim3(512), 0, (hipStream_t)stream, (const bf16*)qkv,
+                       (bf16*)out, lse, H, sl, L_valid);
+    return mdt_check_launch("attn_fwd_res");
   }
   // two query fragments per wave pay off for the narrow heads (hd <= 64: -8..-10 %); at hd 72/80 the
   // extra registers cost occupancy and the kernel is bound by its 144-byte-segment global reads anyway
@@ -1577,6 +1779,15 @@ extern "C" int mdt_attn_bwd(const mdt_bf16* qkv, const mdt_bf16* out, const mdt_
     int rc = mdt_check_launch("attn_bwd_q_res");
     if (rc) return rc;
     hipLaunchKernelGGL((attn_bwd_kv_res_kernel<72, 4>), dim3(1, B * H), dim3(512), 0, (hipStream_t)stream, (const bf16*)qkv,
+                       (const bf16*)dout, lse, delta, (bf16*)dqkv, H, sc, sl, L_valid);
+    return mdt_check_launch("attn_bwd_kv_res");
+  }
+  if (L == 1024 && hd == 32 && sp_knob != 1) {  // the same two resident-tile kernels on the swizzled 64-byte image
+    hipLaunchKernelGGL((attn_bwd_q_res_kernel<32, 8>), dim3(1, B * H), dim3(512), 0, (hipStream_t)stream, (const bf16*)qkv,
+                       (const bf16*)out, (const bf16*)dout, lse, delta, (bf16*)dqkv, H, sc, sl, L_valid);
+    int rc = mdt_check_launch("attn_bwd_q_res");
+    if (rc) return rc;
+    hipLaunchKernelGGL((attn_bwd_kv_res_kernel<32, 8>), dim3(1, B * H), dim3(512), 0, (hipStream_t)stream, (const bf16*)qkv,
                        (const bf16*)dout, lse, delta, (bf16*)dqkv, H, sc, sl, L_valid);
     return mdt_check_launch("attn_bwd_kv_res");
   }

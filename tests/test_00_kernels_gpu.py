@@ -389,7 +389,8 @@ def test_gemm_tn_asymmetric_and_edges():
 # ------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('B_,L,H,hd', [(2, 128, 3, 72), (2, 256, 4, 32), (1, 128, 2, 64), (1, 64, 1, 80), (1, 512, 2, 72),
                                         (9, 128, 2, 80), (3, 256, 2, 72), (2, 256, 1, 64), (10, 128, 2, 32), (1, 256, 2, 80),
-                                        (40, 128, 16, 72), (33, 128, 8, 72)])  # 640 / 264 items: 2-3 per persistent workgroup
+                                        (40, 128, 16, 72), (33, 128, 8, 72),  # 640 / 264 items: 2-3 per persistent workgroup
+                                        (2, 1024, 3, 32), (1, 1024, 16, 32)])  # round 5: the 512^2 decoder -- K / V (Q / dO) resident, online softmax
 # 0: product dispatch (L 128 / hd 72: the LDS-DMA double-buffered backward), 1: block-loop kernels everywhere,
 # 2: single-pass everywhere (2 WG/CU bwd build), 3: register-prefetch single-pass backward instead of the LDS-DMA one
 @pytest.mark.parametrize('sp', [0, 1, 2, 3])
@@ -401,8 +402,8 @@ def test_attention_fwd_bwd(B_, L, H, hd, sp):
     q32 = qkv.float().reshape(B_, L, 3, H, hd).permute(2, 0, 3, 1, 4).contiguous().requires_grad_(True)
     o_ref = F.scaled_dot_product_attention(q32[0], q32[1], q32[2])
     o_ref2 = o_ref.transpose(1, 2).reshape(B_ * L, D)
-    if sp and L not in (128, 256) and not (L == 512 and hd == 72 and sp == 1):
-        pytest.skip('the knob only matters at L = 128 / 256 (and, forward only, at L = 512 / hd 72)')
+    if sp and L not in (128, 256) and not (sp == 1 and ((L == 512 and hd == 72) or (L == 1024 and hd == 32))):
+        pytest.skip('the knob only matters at L = 128 / 256 (and, as 0 / 1, at L = 512 / hd 72 and L = 1024 / hd 32)')
     if sp == 3 and not (L == 128 and hd == 72):
         pytest.skip('knob 3 only differs from 0 where the LDS-DMA backward exists')
     _lib.lib().mdt_set_tuning(b'attn_sp', sp)
@@ -630,7 +631,7 @@ def test_ln_modulate_fwd_bwd(B_, L, D):
     close(dx2, x.grad, 1e-4, 'ln_mod dx (overwrite)')
 
 
-@pytest.mark.parametrize('L,Lv,hd', [(192, 179, 64), (128, 100, 72), (256, 179, 32), (128, 65, 64), (256, 193, 72), (512, 449, 72)])
+@pytest.mark.parametrize('L,Lv,hd', [(192, 179, 64), (128, 100, 72), (256, 179, 32), (128, 65, 64), (256, 193, 72), (512, 449, 72), (1024, 897, 32)])
 def test_attention_padded_keys(L, Lv, hd):
     """L_valid < L: rows >= L_valid are padding -- zero probability as keys; with dout = 0 on them the
     whole dqkv of those rows is exactly zero and the valid rows match an attention over L_valid tokens

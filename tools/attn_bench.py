@@ -30,10 +30,10 @@ def main(iters=20):
 
     print(f'{"shape (B,L,H,hd)":26s} {"variant":>10s} {"fwd us":>8s} {"bwd us":>8s} {"fwd GB/s":>9s} {"bwd GB/s":>9s} {"fwd TF/s":>9s}')
     # the benchmarked shapes: encoder (B 1024, L 128, hd 72) and decoder (B 1024, T 256, hd 32) of XL/2 at 256^2
-    for B, L, H, hd in [(1024, 128, 16, 72), (1024, 256, 16, 32), (64, 512, 16, 72), (128, 256, 16, 72)]:
+    for B, L, H, hd in [(1024, 128, 16, 72), (1024, 256, 16, 32), (64, 512, 16, 72), (128, 256, 16, 72), (256, 1024, 16, 32)]:
         qkv = (torch.randn(B * L, 3 * H * hd, device=dev) * 0.5).to(torch.bfloat16)
         for sp, name in ((1, 'block-loop'), (0, 'default'), (2, 'sp OCC=4')):
-            if sp != 1 and L not in (128, 256, 512):
+            if (sp != 1 and L not in (128, 256, 512, 1024)) or (sp == 2 and L > 256):
                 continue
             L_.mdt_set_tuning(b'attn_sp', sp)
             out, lse = ops.attn_fwd(qkv, B, L, H, hd)

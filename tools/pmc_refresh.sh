@@ -3,7 +3,7 @@
 # Separate rocprofv3 --pmc passes of the benchmarked command (TCC: FETCH_SIZE needs 3 of the 4 slots; never combined with
 # trace domains other than the kernel trace), summaries written under gpurun_out/<tag>/ for copying into profiles/.
 set -u
-TAG=${1:-r4}
+TAG=${1:-r5}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/$TAG
@@ -19,7 +19,7 @@ run_pass sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE
 run_pass lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_LDS GRBM_GUI_ACTIVE
 F=$(find $OUT/pmc_fetch -name "*.db" | head -1)
 W=$(find $OUT/pmc_write -name "*.db" | head -1)
-python tools/pmc_summary.py $F $W $OUT/pmc_gemm_nt.json $OUT/pmc_hbm_traffic.txt DiT-XL/2 32 1024 "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- $CMD (round 4, separate passes)" > /dev/null
+python tools/pmc_summary.py $F $W $OUT/pmc_gemm_nt.json $OUT/pmc_hbm_traffic.txt DiT-XL/2 32 1024 "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -- $CMD (separate passes)" > /dev/null
 python tools/pmc_table.py $OUT/pmc_write $OUT/pmc_sq $OUT/pmc_lds > $OUT/pmc_counters.txt 2>&1
 # L2-miss latency (tools/mall_probe.py): the benchmarked step and the HBM / Infinity-Cache calibration kernels
 run_pass lat TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_DRAM_sum
