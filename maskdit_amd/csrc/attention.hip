@@ -284,18 +284,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16* __restrict__ 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           // keys >= Lv are padding rows (kept-token count rounded up to the 64-row tile): no probability mass
-          s[qi][f][r] = (kb + 16 * f + 4 * g + r < Lv) ? s[qi][f][r] * scale_log2e : -1e30f;
+          // (round 5: scale folded into the exp2 fma, hardware exp2 -- see attn_fwd_sp_kernel; the select stays per score
+          // here, this is the fallback kernel)
+          s[qi][f][r] = (kb + 16 * f + 4 * g + r < Lv) ? s[qi][f][r] : -1e30f;
           mx = fmaxf(mx, s[qi][f][r]);
         }
-      mx = group_max(mx);
+      mx = group_max(mx) * scale_log2e;
       const float m_new = fmaxf(m_run[qi], mx);
-      const float alpha = exp2f(m_run[qi] - m_new);
+      const float alpha = fast_exp2(m_run[qi] - m_new);
       float psum = 0.f;
 #pragma unroll
       for (int f = 0; f < 4; ++f)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float pv = exp2f(s[qi][f][r] - m_new);
+          float pv = fast_exp2(__builtin_fmaf(s[qi][f][r], scale_log2e, -m_new));
           s[qi][f][r] = pv;
           psum += pv;
         }
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const bf16* __restrict
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float pv = (kb + 16 * f + 4 * g + r < Lv) ? exp2f(s[r] * scale_log2e - my_lse) : 0.f;
+        float pv = (kb + 16 * f + 4 * g + r < Lv) ? fast_exp2(__builtin_fmaf(s[r], scale_log2e, -my_lse)) : 0.f;
         ds[f][r] = pv * (dp[r] - dl) * scale;
       }
     }
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const bf16* __restric
       f32x4 dl = *(const f32x4*)(del_s + 16 * f + 4 * g);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float pv = (k0 + i16 < Lv) ? exp2f(s[r] * scale_log2e - ls[r]) : 0.f;  // this lane's key column
+        float pv = (k0 + i16 < Lv) ? fast_exp2(__builtin_fmaf(s[r], scale_log2e, -ls[r])) : 0.f;  // this lane's key column
         pm[f][r] = pv;
         ds[f][r] = pv * (dp[r] - dl[r]) * scale;
       }
