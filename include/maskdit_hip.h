@@ -42,6 +42,9 @@ int mdt_lds_poison(void* sink4, mdt_stream_t stream);
  * launch are garbage).  stats16 (may be NULL): stall-clock sums of its STATS launches (experiments build).  HOST
  * pointers; synchronises the device; reset != 0 clears both afterwards. */
 int mdt_nt8o_report(unsigned* abort_code, unsigned long long* stats16, int reset);
+/* ... and the per-tile time line of workgroup 0 of its last STATS launch: [role 0 MMA | 1 loader | 2 epilogue][tile < 32][start, done]
+ * shader-clock stamps (192 values, HOST pointer; synchronises the device). */
+int mdt_nt8o_stamps(unsigned long long* host192);
 
 /* ---------------------------------------------------------------- GEMMs (MFMA bf16) ---- */
 

@@ -94,6 +94,7 @@ _PLAIN = {
     'mdt_event_destroy': [vp],
     'mdt_set_tuning': [C.c_char_p, i32],
     'mdt_nt8o_report': [C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), i32],
+    'mdt_nt8o_stamps': [C.POINTER(C.c_uint64)],
 }
 EXPORTED = sorted(list(_PROTOS) + list(_PLAIN) + ['mdt_last_error', 'mdt_version'])
 ABI_VERSION = 3  # == MDT_ABI_VERSION of include/maskdit_hip.h (tests/test_capi_cpu.py compares the two)

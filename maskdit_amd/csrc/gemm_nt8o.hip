@@ -81,6 +81,10 @@ enum { S_MMA_FULL = 0, S_LD_EMPTY = 3, S_EP_DUMP = 5, S_MMA_TOTAL = 6, S_EP_TOTA
 static __device__ float nt8o_zero_row[1024 + 64];                        // stands in for a NULL bias (zero-initialised)
 static __device__ unsigned nt8o_abort;                                   // != 0: some wave gave up a bounded spin
 static __device__ unsigned long long nt8o_stats[nt8o::S_COUNT];
+// STATS launches: shader-clock stamps of workgroup 0, per role (0 MMA wave 0, 1 loader 0, 2 epilogue wave 0) and tile (first 32):
+// [0] = the role starts the tile (MMA: first MFMA phase; loader: first piece issued; epilogue: tile published and picked up),
+// [1] = it is done with it (MMA: K loop finished, y stores about to issue; loader: last piece issued; epilogue: last store issued)
+static __device__ unsigned long long nt8o_stamps[3 * 32 * 2];
 
 namespace nt8o {
 
@@ -265,6 +269,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8o_kernel(NTParams p) {
     }                                                                                                               \
     __builtin_amdgcn_sched_barrier(0);                                                                              \
   }
+      if (STATS && blockIdx.x == 0 && wave == 0 && lane == 0 && T < 32) nt8o_stamps[(0 * 32 + T) * 2] = __builtin_readcyclecounter();
       for (int kt = 0; kt < nk; ++kt) {
         const int stn = st == NS - 1 ? 0 : st + 1;
         const unsigned usen = use + (stn == 0 ? 1u : 0u);
@@ -295,6 +300,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8o_kernel(NTParams p) {
         use = usen;
       }
 #undef NT8O_PHASE
+      if (STATS && blockIdx.x == 0 && wave == 0 && lane == 0 && T < 32) nt8o_stamps[(0 * 32 + T) * 2 + 1] = __builtin_readcyclecounter();
       // ---- y = bf16(acc + bias) goes to `out` from HERE, as plain stores nobody waits for: 16 x 1 KiB per wave, then
       // straight on to the next tile's K loop (its first fragments are already in registers)
       if (!(DBG & DBG_NO_YSTORE)) {
@@ -372,6 +378,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8o_kernel(NTParams p) {
       }                                                          \
     }                                                            \
   }
+        if (STATS && blockIdx.x == 0 && L == 0 && lane == 0 && T < 32 && kt == 0) nt8o_stamps[(1 * 32 + T) * 2] = __builtin_readcyclecounter();
         NT8O_PIECES(0, NP / 2)
         if (!first) {
           // NP / 2 pieces of THIS K-tile may be in flight; loads retire in order, so everything older -- the previous
@@ -381,6 +388,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8o_kernel(NTParams p) {
         }
         NT8O_PIECES(NP / 2, NP)
 #undef NT8O_PIECES
+        if (STATS && blockIdx.x == 0 && L == 0 && lane == 0 && T < 32 && kt == nk - 1) nt8o_stamps[(1 * 32 + T) * 2 + 1] = __builtin_readcyclecounter();
         first = false;
         st_prev = st;
         st = st == NS - 1 ? 0 : st + 1;
@@ -430,6 +438,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8o_kernel(NTParams p) {
       if constexpr (E == E_ACT) {
         constexpr int D = 24;
         wait_ge<STATS>(flags, F_YDONE, 4u * (unsigned)(T + 1), lane, st_a, gave_up);
+        if (STATS && blockIdx.x == 0 && e == 0 && lane == 0 && T < 32) nt8o_stamps[(2 * 32 + T) * 2] = __builtin_readcyclecounter();
         const unsigned la = (unsigned)(r4 * p.ldo2 + 8 * c) * 2u;
         auto body = [&](auto is_gelu) {
           constexpr bool GELU = decltype(is_gelu)::value;
@@ -477,6 +486,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8o_kernel(NTParams p) {
         for (int G = 0; G < D; ++G) ldr(G);
         __builtin_amdgcn_sched_barrier(0);
         wait_ge<STATS>(flags, F_YDONE, 4u * (unsigned)(T + 1), lane, st_a, gave_up);
+        if (STATS && blockIdx.x == 0 && e == 0 && lane == 0 && T < 32) nt8o_stamps[(2 * 32 + T) * 2] = __builtin_readcyclecounter();
 #pragma unroll
         for (int G = 0; G < D; ++G) ldy(G);
         __builtin_amdgcn_sched_barrier(0);
@@ -498,6 +508,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8o_kernel(NTParams p) {
           __builtin_amdgcn_sched_barrier(0);  // (otherwise hipcc hoists every load of the tile to the top and spills)
         }
       }
+      if (STATS && blockIdx.x == 0 && e == 0 && lane == 0 && T < 32) nt8o_stamps[(2 * 32 + T) * 2 + 1] = __builtin_readcyclecounter();
     }
     if (STATS && lane == 0 && wave == 4 + NL) {
       atomicAdd(&nt8o_stats[S_EP_DUMP], st_a);
@@ -564,6 +575,12 @@ int launch_gemm_nt8o(const NTParams& p, int nl, int dbg, hipStream_t stream) {
     default: mdt_set_error("gemm_nt8o: no overlap form for this epilogue"); return MDT_ERR_ARG;
   }
   return mdt_check_launch("gemm_nt8o");
+}
+
+// tools/nt8o_bench.py --stamps: the per-tile time line of workgroup 0 written by the last STATS launch (3 roles x 32 tiles x 2)
+extern "C" int mdt_nt8o_stamps(unsigned long long* host192) {
+  if (hipDeviceSynchronize() != hipSuccess) return MDT_ERR_LAUNCH;
+  return hipMemcpyFromSymbol(host192, HIP_SYMBOL(nt8o_stamps), sizeof(unsigned long long) * 192) == hipSuccess ? MDT_OK : MDT_ERR_LAUNCH;
 }
 
 // Host-side report of the overlap kernel's bounded-spin guard and (STATS launches) stall clocks.  Synchronises the

@@ -153,6 +153,17 @@ def main():
             print(f'{"":38s}nl{2 if ovb == 3 else 3}   stalls: MMA waits for operands {s[0] / max(s[6], 1):.3f} of its {s[6] / w:.0f} clocks; loader waits for a free stage '
                   f'{s[3] / max(s[8], 1):.3f} of {s[8] / w:.0f}; epilogue waits for the tile {s[5] / max(s[7], 1):.3f} of {s[7] / max(w, 1):.0f}'
                   + (f'   ABORT {code}' if code else ''), flush=True)
+          if name == 'GATE_RES' and ovb == 3 and 'proj' in tag or (name == 'GATE_RES' and ovb == 3 and 'fc2 fwd' == tag):
+            stp = (C.c_uint64 * 192)()
+            assert L.mdt_nt8o_stamps(stp) == 0
+            t0 = stp[0]
+            rows = []
+            for T in range(2, 8):  # steady-state tiles of workgroup 0
+                rel = [int(stp[(r * 32 + T) * 2 + e]) - int(t0) for r in range(3) for e in range(2)]
+                rows.append(f'tile {T}: MMA K loop [{rel[0]:7d}, {rel[1]:7d}]  loader issues [{rel[2]:7d}, {rel[3]:7d}]  epilogue [{rel[4]:7d}, {rel[5]:7d}]')
+            print(f'{"":38s}nl2   time line of workgroup 0 (shader clocks from its first MFMA phase; the epilogue of tile T runs under the K loop of tile T + 1):')
+            for r_ in rows:
+                print(f'{"":44s}{r_}', flush=True)
         del A, Wt, kw, o
         torch.cuda.empty_cache()
     tune()
