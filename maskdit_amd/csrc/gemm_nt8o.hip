@@ -34,7 +34,12 @@
 // that is already satisfied costs one broadcast ds_read issued a phase earlier.
 //   full[s]   += 1 by each loader when its share of a fill of stage s has landed   (fill n ready   <=> full[s]  == NL n)
 //   empty[s]  += 1 by each MMA wave after its last read of a fill of stage s       (fill n drained <=> empty[s] == 4 n)
-//   ydone     += 1 by each MMA wave once its y stores of a tile are acknowledged    (tile T in L2   <=> ydone == 4 (T + 1))
+//   ydone[w]  += 1 by MMA wave w once its y stores of a tile are acknowledged      (tile T in L2   <=> every ydone[w] >= T + 1)
+// (ONE word per MMA wave: with a single summed counter, two waves that have finished the workgroup's last tile and
+// published it could lift the sum over the threshold of the tile BEFORE while the other two waves -- up to three K-tiles
+// behind, the ring allows that -- had not acknowledged theirs: possible for K < 512, found by the exhaustive interleaving
+// check tools/nt8o_protocol_model.py, never observed on hardware.  full / empty are exact by construction: nobody can add
+// for fill n + 1 of a stage before everybody has added for fill n.)
 // Every spin is bounded; a wave that gives up poisons every counter (all later waits fall through, results garbage, the
 // launch terminates) and raises nt8o_abort, which mdt_nt8o_report returns -- a protocol bug must not hang the GPU.
 //
@@ -67,7 +72,7 @@ constexpr int A_BYTES = BM * 128;         // 256 rows x 64 bf16
 constexpr int B_BYTES = BN * 128;
 constexpr int STAGE = A_BYTES + B_BYTES;  // 48 KiB
 constexpr int NS = 3;
-enum { F_FULL = 0, F_EMPTY = 4, F_YDONE = 8, F_COUNT = 16 };
+enum { F_FULL = 0, F_EMPTY = 4, F_YDONE = 8 /* .. 11: one per MMA wave */, F_COUNT = 16 };
 constexpr unsigned POISON = 0x40000000u;
 constexpr int SPIN_LIMIT = 1 << 15;       // x (~64-clock nap + LDS round trip) ~ 3 ms
 constexpr int DEPTH = 14;                 // GATE epilogue look-ahead in 4-row groups (12 registers each: 2 x 16 B residual + 16 B y per lane)
@@ -152,6 +157,30 @@ __device__ __forceinline__ void wait_ge(unsigned flags0, int idx, unsigned need,
   wait_ge<STATS>(flags0, idx, need, flag_ld(flags0 + 4u * idx), lane, stall, gave_up);
 }
 
+// ... until FOUR consecutive counters (idx .. idx + 3, 16-byte aligned) are all >= need: the per-MMA-wave ydone words
+template <bool STATS>
+__device__ __forceinline__ void wait_ge4(unsigned flags0, int idx, unsigned need, int lane, unsigned long long& stall, unsigned& gave_up) {
+  unsigned long long t0 = 0;
+  bool timed = false;
+  int it = 0;
+  for (; it < SPIN_LIMIT; ++it) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(flags0 + 4u * idx) : "memory");
+    const unsigned m = min(min(v[0], v[1]), min(v[2], v[3]));
+    if (__builtin_amdgcn_readfirstlane(m) >= need) break;
+    if (STATS && !timed) {
+      t0 = __builtin_readcyclecounter();
+      timed = true;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  if (it == SPIN_LIMIT) {
+    if (lane < F_COUNT) asm volatile("ds_write_b32 %0, %1" ::"v"(flags0 + 4u * lane), "v"(POISON) : "memory");
+    gave_up = 1u + (unsigned)idx;
+  }
+  if (STATS && timed) stall += __builtin_readcyclecounter() - t0;
+}
+
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
   bf16x2 t;
   t[0] = f2bf(lo);
@@ -181,7 +210,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8o_kernel(NTParams p) {
   static_assert(NL >= 2 && NL <= 4 && (E == E_PLAIN) == (NL == 4), "role split");
   constexpr bool STATS = (DBG & DBG_STATS) != 0;
   __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
-  __shared__ unsigned flags_mem[F_COUNT];
+  __shared__ __attribute__((aligned(16))) unsigned flags_mem[F_COUNT];  // (ydone[0..3] are read with one ds_read_b128)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -283,7 +312,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8o_kernel(NTParams p) {
         }
         if (E != E_PLAIN && T > 0 && kt == sig_kt) {  // tile T - 1 is in L2: hand it to the epilogue waves
           wait_vmcnt<0>();
-          flag_add(flags + 4u * F_YDONE);
+          flag_add(flags + 4u * (F_YDONE + wave));
         }
         unsigned seen = 0;
         NT8O_PHASE(0)
@@ -330,7 +359,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8o_kernel(NTParams p) {
     }
     if (E != E_PLAIN) {  // the last tile
       wait_vmcnt<0>();
-      flag_add(flags + 4u * F_YDONE);
+      flag_add(flags + 4u * (F_YDONE + wave));
     }
     if (STATS && lane == 0 && wave == 0) {
       atomicAdd(&nt8o_stats[S_MMA_FULL], st_a);
@@ -437,7 +466,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8o_kernel(NTParams p) {
       auto ldy = [&](int G) { Y[G] = *(const u32x4*)(rows(p.out, p.ldo, 2, G) + opaque(ly)); };
       if constexpr (E == E_ACT) {
         constexpr int D = 24;
-        wait_ge<STATS>(flags, F_YDONE, 4u * (unsigned)(T + 1), lane, st_a, gave_up);
+        wait_ge4<STATS>(flags, F_YDONE, (unsigned)(T + 1), lane, st_a, gave_up);
         if (STATS && blockIdx.x == 0 && e == 0 && lane == 0 && T < 32) nt8o_stamps[(2 * 32 + T) * 2] = __builtin_readcyclecounter();
         const unsigned la = (unsigned)(r4 * p.ldo2 + 8 * c) * 2u;
         auto body = [&](auto is_gelu) {
@@ -462,7 +491,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8o_kernel(NTParams p) {
         };
         if (act == MDT_EPI_GELU) body(TT{}); else body(FF{});
       } else {  // E_GATE: outf = res + gate[sample] * y.  rows_per_sample % 64 == 0: one sample per 64-row half
-        constexpr int D = DEPTH;
+        constexpr int D = NE == 1 ? DEPTH - 2 : DEPTH;  // (one epilogue wave holds four gate rows: 16 registers more)
         const unsigned lr_ = (unsigned)(r4 * p.ldres + 8 * c) * 4u, lf = (unsigned)(r4 * p.ldof + 8 * c) * 4u;
         f32x4 gate[ROWS / 64][2];
 #pragma unroll
@@ -485,7 +514,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8o_kernel(NTParams p) {
 #pragma unroll
         for (int G = 0; G < D; ++G) ldr(G);
         __builtin_amdgcn_sched_barrier(0);
-        wait_ge<STATS>(flags, F_YDONE, 4u * (unsigned)(T + 1), lane, st_a, gave_up);
+        wait_ge4<STATS>(flags, F_YDONE, (unsigned)(T + 1), lane, st_a, gave_up);
         if (STATS && blockIdx.x == 0 && e == 0 && lane == 0 && T < 32) nt8o_stamps[(2 * 32 + T) * 2] = __builtin_readcyclecounter();
 #pragma unroll
         for (int G = 0; G < D; ++G) ldy(G);

@@ -445,3 +445,24 @@ def test_plan_cache_evicts_least_recently_used_across_engines():
             E.LIVE_ENGINES.discard(e)
         for e in saved:
             E.LIVE_ENGINES.add(e)
+
+
+def test_nt8o_counter_protocol_model():
+    """csrc/gemm_nt8o.hip synchronises its MMA / loader / epilogue waves through monotonic LDS counters instead of
+    s_barrier.  tools/nt8o_protocol_model.py restates each role's walk (same order of waits, adds, fragment reads and LDS-DMA
+    issues, same use counters and thresholds) and explores EVERY interleaving of the roles and of the asynchronous, per-loader
+    in-order DMA completions for small parameters: no deadlock, no fragment read before all loaders' pieces of that fill have
+    landed or after the stage is being overwritten, no refill before every MMA wave has finished the previous fill, no tile
+    picked up by an epilogue wave before every MMA wave's y stores of it were acknowledged -- across tile boundaries, for
+    K-tile counts that are and are not multiples of the ring depth, 1-3 loaders, with and without epilogue waves.  The FIRST
+    form of the kernel (one summed ydone counter) must fail the check: it does, at the workgroup's last tile."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('nt8o_protocol_model', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools',
+                                                                                     'nt8o_protocol_model.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for cfg in (dict(W=2, NL=2, NE=1, nk=4, tiles=2), dict(W=2, NL=2, NE=1, nk=5, tiles=2), dict(W=2, NL=1, NE=0, nk=7, tiles=2),
+                dict(W=2, NL=2, NE=2, nk=4, tiles=2), dict(W=1, NL=3, NE=1, nk=4, tiles=3)):
+        assert mod.check(**cfg) > 1000
+    with pytest.raises(AssertionError, match='acknowledged its y stores'):
+        mod.check(W=2, NL=2, NE=1, nk=4, tiles=2, summed_ydone=True)
