@@ -559,7 +559,9 @@ def test_gemm_pipelines_poisoned_lds_stress(M, N, K, cus):
                                                (2048, 384, 512, 'GATE_RES', 64, 5),       # 24 tiles on 5 workgroups (uneven), a gate row per 64-row half
                                                (4096, 1152, 1152, 'GATE_RES', 128, 24),   # the XL/2 proj shape, 6 tiles per workgroup
                                                (2048, 512, 256, 'GELU', 128, 3), (2304, 1152, 4608, 'GELU', 128, 0),
-                                               (1536, 384, 320, 'BF16', 128, 4), (8192, 3456, 1152, 'BF16', 128, 0)])
+                                               (1536, 384, 320, 'BF16', 128, 4), (8192, 3456, 1152, 'BF16', 128, 0),
+                                               (32768, 1152, 4608, 'GATE_RES', 128, 0),   # production rows: 4.5 tiles per workgroup, 72 K-tiles each
+                                               (2048, 256, 256, 'GATE_RES', 128, 2)])     # K = 256: the shortest walk, 8 tiles per workgroup (the per-wave ydone case)
 def test_gemm_nt8o_wave_specialised_bit_identical(M, N, K, epi, Lr, cus):
     """csrc/gemm_nt8o.hip (the epilogue-under-the-K-loop form with MMA / loader / epilogue WAVES that
     synchronise through LDS counters) against the product gemm_nt8 on the same inputs: every output BIT-identical, with two
