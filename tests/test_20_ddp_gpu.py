@@ -116,6 +116,66 @@ def test_two_rank_data_parallel(backend):
     print('worst DP-vs-full-batch grad rel err', max(r[2] for r in res))
 
 
+def _rccl_forms_worker(port, q):
+    """ONE rank, backend nccl (= RCCL): the only RCCL execution a 1-GPU box allows (two ranks on one device are refused:
+    "Duplicate GPU detected").  It cannot show link behaviour, but it does run the exact CALL FORMS of the data-parallel path
+    through RCCL's argument checks and kernels: asynchronous AVG all-reduce on an arena view, in-place reduce_scatter_tensor
+    whose output is a view of its input, the bf16 staging wire, in-place all_gather_into_tensor into the arena."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+    torch.cuda.set_device(0)
+    try:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+        from maskdit_amd.ddp import GradSlabReducer, slab_pieces
+        flat = torch.randn(1 << 16, device='cuda')
+        ref = flat.clone()
+        r = GradSlabReducer()
+        assert r.backend == 'nccl' and r.world == 1
+        r.attach(flat)
+        r._launch(128, 40000)                                   # all_reduce(AVG), async
+        qq, pieces, tail = slab_pieces(40000, 65000, 1)
+        r._launch(40000, 40000 + qq, scatter_q=qq)             # in-place reduce_scatter_tensor(AVG)
+        r.finish()
+        torch.cuda.synchronize()
+        assert not r.plain_only, 'RCCL refused a call form and the reducer degraded'
+        assert torch.equal(flat, ref) and r.wire_bytes == (40000 - 128 + qq) * 4
+        rb = GradSlabReducer(wire_dtype=torch.bfloat16)         # the staging arena is only allocated for world > 1: give it one
+        rb.attach(flat)
+        rb.stage = torch.empty(flat.numel(), device='cuda', dtype=torch.bfloat16)
+        rb._launch(0, 4096)
+        rb.finish()
+        torch.cuda.synchronize()
+        assert torch.equal(flat[:4096], ref[:4096].to(torch.bfloat16).float()) and torch.equal(flat[4096:], ref[4096:])
+        w = dist.all_gather_into_tensor(flat[8192:8192 + 1024], flat[8192:8192 + 1024], async_op=True)  # zero.py's parameter gather form
+        w.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(flat[8192:9216], ref[8192:9216])
+        q.put('ok NCCL ' + '.'.join(map(str, torch.cuda.nccl.version())))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put('FAIL: ' + traceback.format_exc())
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_rccl_call_forms_on_a_single_rank_group():
+    """No multi-GPU node has been available in rounds 1-5, so RCCL had never executed a line of this repo's exchange.  A
+    world-size-1 nccl group on the one GPU runs every collective FORM the path uses (see the worker) -- an argument-level
+    refusal (ReduceOp.AVG, in-place views, bf16) would show here instead of on the first 8-GPU run."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_forms_worker, args=(29900 + (os.getpid() % 90), q))
+    p.start()
+    res = q.get(timeout=240)
+    p.join(60)
+    assert res.startswith('ok'), res
+    print('single-rank RCCL group:', res)
+
+
 def _zero_worker(rank, world, port, q):
     """ZeRO-1 (maskdit_amd/zero.py): reduce-scattered gradient slabs (rank r owns piece r of every slab) + sharded
     AdamW/EMA + parameter all-gather must give the unsharded result."""
