@@ -5,7 +5,9 @@ Same inputs, same thread count, same step: XL/2, 256^2 latents, batch 16, mask 0
                 adam_w_mode, wd 0) -> train_utils/helper.update_ema                (train.py:216-230)
     port      : oracle.maskdit_oracle.train_step (the function bench.py times)
 and the two losses are compared, so the record also shows the port computes the reference's numbers.
-    python tools/ref_vs_port_cpu.py [--threads 8] [--steps 3] > profiles/r5_cpu_reference_vs_port.txt"""
+    python tests/golden/ref_vs_port_cpu.py [--threads 8] [--steps 3] > profiles/r5_cpu_reference_vs_port.txt
+(lives next to make_golden.py: like it, it is test infrastructure that imports the reference and the oracle; nothing under tools/ or
+the product package does.)"""
 import argparse
 import copy
 import os
@@ -14,7 +16,7 @@ import time
 
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
 import make_golden as G  # noqa: E402  (imports the reference through the timm / lmdb shims)
