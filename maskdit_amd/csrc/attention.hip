@@ -839,16 +839,19 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_res_kernel(const bf16* __rest
         }
       }
       bf16x8 pf[QF][KB / 32];
+      // vector-ALU work per score: max, one fma (the softmax scale is folded into the exp2 argument), exp2, add -- and the
+      // padding select (keys >= Lv: no probability mass) only in the steps that reach past Lv (wave-uniform, ONE branch per
+      // step in front of the query-block loop, which stays a single scheduling region)
+      if (kb + KB > Lv) {
 #pragma unroll
-      for (int qi = 0; qi < QF; ++qi) {
-        // vector-ALU work per score: max, one fma (the softmax scale is folded into the exp2 argument), exp2, add --
-        // and the padding select (keys >= Lv: no probability mass) only in the steps that reach past Lv (wave-uniform)
-        if (kb + KB > Lv) {
+        for (int qi = 0; qi < QF; ++qi)
 #pragma unroll
           for (int f = 0; f < KB / 16; ++f)
 #pragma unroll
             for (int r = 0; r < 4; ++r) s[qi][f][r] = (kb + 16 * f + 4 * g + r < Lv) ? s[qi][f][r] : -1e30f;
-        }
+      }
+#pragma unroll
+      for (int qi = 0; qi < QF; ++qi) {
         float mx = -1e30f;
 #pragma unroll
         for (int f = 0; f < KB / 16; ++f)
@@ -1115,10 +1118,13 @@ __global__ __launch_bounds__(512, OCC) void attn_bwd_sp_kernel(const bf16* __res
             const float pv = fast_exp2(__builtin_fmaf(s[r], scale_log2e, -my_lse));
             ds[f][r] = pv * __builtin_fmaf(dp[r], scale, -dl);  // dl = delta * scale
           }
-          if (kb + 64 > Lv) {  // (wave-uniform: only key blocks that reach past Lv pay for the padding select)
+        }
+        if (kb + 64 > Lv) {  // wave-uniform, ONE branch per key block, behind the fragment loop (a branch per fragment would cut
+                             // the loop into four scheduling regions): only key blocks that reach past Lv pay for the padding select
+#pragma unroll
+          for (int f = 0; f < 4; ++f)
 #pragma unroll
             for (int r = 0; r < 4; ++r) ds[f][r] = (kb + 16 * f + 4 * g + r < Lv) ? ds[f][r] : 0.f;
-          }
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -1241,10 +1247,12 @@ __device__ __forceinline__ void attn_bwd_item_math(const char* Qs, const char* K
           const float pv = fast_exp2(__builtin_fmaf(s[r], scale_log2e, -my_lse));
           ds[f][r] = pv * __builtin_fmaf(dp[r], scale, -dl);  // dl = delta * scale
         }
-        if (kb + 64 > Lv) {  // (wave-uniform: only key blocks that reach past Lv pay for the padding select)
+      }
+      if (kb + 64 > Lv) {  // wave-uniform, ONE branch per key block (see attn_bwd_sp_kernel)
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
 #pragma unroll
           for (int r = 0; r < 4; ++r) ds[f][r] = (kb + 16 * f + 4 * g + r < Lv) ? ds[f][r] : 0.f;
-        }
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -1525,10 +1533,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_q_res_kernel(const bf16* __re
           const float pv = fast_exp2(__builtin_fmaf(sv[r], scale_log2e, -my_lse));
           ds[f][r] = pv * __builtin_fmaf(dp[r], scale, -dl_s);
         }
-        if (kb + 64 > Lv) {
+      }
+      if (kb + 64 > Lv) {  // wave-uniform, ONE branch per key block
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
 #pragma unroll
           for (int r = 0; r < 4; ++r) ds[f][r] = (kb + 16 * f + 4 * g + r < Lv) ? ds[f][r] : 0.f;
-        }
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
