@@ -1655,6 +1655,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_kv_res_kernel(const bf16* __r
     }
     bf16* drow = dqkv + ((long)b * L + k0 + i16) * ld + h * HD;
     AttnRow<HD> krw, vrw;
+    if (key_pen != 0.f) {  // padding key column: hard zeros, as in attn_bwd_sp_kernel -- the penalty alone gives exact zeros
+                           // only while the padding rows of K / Q and the lse are finite
+#pragma unroll
+      for (int f = 0; f < C::NFRAG; ++f) dk[f] = dv[f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
     attn_pack_row<HD>(krw, dk);
     attn_pack_row<HD>(vrw, dv);
     attn_store_row<HD>(drow + D, g, krw);

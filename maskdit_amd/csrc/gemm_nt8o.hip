@@ -544,7 +544,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt8o_kernel(NTParams p) {
       atomicAdd(&nt8o_stats[S_EP_TOTAL], __builtin_readcyclecounter() - t_begin);
     }
   }
-  if (gave_up && lane == 0) __hip_atomic_store(&nt8o_abort, gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (gave_up) {
+    if (lane == 0) __hip_atomic_store(&nt8o_abort, gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifndef MDT_EXPERIMENTS
+    // Product library: a wave that gave up a bounded spin has let every other wait of its workgroup fall through, so the
+    // launch's outputs are garbage -- and the launch would still return MDT_OK (only mdt_nt8o_report, a test / tool entry,
+    // reads nt8o_abort).  A training job that selected this A/B form through MDT_TUNE must not continue on corrupted
+    // activations: the wave raises a hardware exception, the queue is torn down and the process ends with the
+    // runtime's "HSA_STATUS_ERROR_EXCEPTION" instead.  (The experiments build keeps running: its tools read the code.)
+    __builtin_trap();
+#endif
+  }
 }
 
 int nt8_num_cus();

@@ -64,7 +64,9 @@ class GradSlabReducer:
         self.reduced_elems = 0
         self.wire_bytes = 0   # bytes handed to the collectives since the last reset (tests / logs)
         self.zero = False
-        self.plain_only = False  # see _degrade()
+        self.plain_only = False   # True when the nccl group agreed to run without AVG / the in-place reduce-scatter
+        self.use_avg = self.use_scatter = False  # collective forms, agreed by all ranks in _agree_forms()
+        self.forms_agreed = False
         self.wire_dtype = wire_dtype if wire_dtype not in (None, torch.float32) else None
         self.stage: Optional[torch.Tensor] = None
 
@@ -72,54 +74,72 @@ class GradSlabReducer:
         self.flat = flat_grad
         if self.wire_dtype is not None and self.world > 1:
             self.stage = torch.empty(flat_grad.numel(), device=flat_grad.device, dtype=self.wire_dtype)
+        if dist.is_initialized() and not self.forms_agreed:  # (also on a one-rank group: the GPU suite runs the RCCL forms that way)
+            self._agree_forms(flat_grad.device, self.wire_dtype or flat_grad.dtype)
 
     def set_zero_sharding(self, on: bool = True):
         self.zero = bool(on)
 
+    # ---- which collective forms this group runs: decided ONCE, by every rank together --------------------------
+    def _agree_forms(self, device, dtype):
+        """The RCCL forms of the exchange (AVG reduction, in-place reduce-scatter on views of one buffer) are probed HERE,
+        once, on a tiny tensor, and the outcome is agreed across the group with a plain all_reduce(SUM) of the success
+        flags: a form is used only if EVERY rank's probe accepted it.  After this point `_launch` catches nothing --
+        a rank-local failure in the middle of training (out of memory, an aborted communicator, a watchdog timeout are
+        all RuntimeErrors) must end the job, not switch ONE rank to a different collective than its peers are in
+        (rounds 1-5 degraded per rank inside `_launch`, which could pair all_reduce(SUM) on one rank with
+        reduce_scatter(AVG) on the others: a hang or silently wrong gradients).  gloo has neither form: SUM + divide."""
+        self.use_avg = self.use_scatter = False
+        if self.backend == 'nccl':
+            flags = [1, 1]
+            probe = torch.ones(8 * self.world, device=device, dtype=dtype)
+            try:
+                dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=self.pg)
+            except (ValueError, NotImplementedError, TypeError, RuntimeError) as e:  # argument-level refusal, same on every rank
+                flags[0] = 0
+                self._note(f'all_reduce(AVG) refused by the backend ({type(e).__name__}: {e})')
+            try:
+                dist.reduce_scatter_tensor(probe[self.rank * 8:(self.rank + 1) * 8], probe, op=dist.ReduceOp.AVG if flags[0] else dist.ReduceOp.SUM,
+                                           group=self.pg)
+            except (ValueError, NotImplementedError, TypeError, RuntimeError) as e:
+                flags[1] = 0
+                self._note(f'in-place reduce_scatter_tensor refused by the backend ({type(e).__name__}: {e})')
+            agreed = torch.tensor(flags, device=device, dtype=torch.int32)
+            dist.all_reduce(agreed, op=dist.ReduceOp.SUM, group=self.pg)  # the plainest form: what the fallback itself uses
+            ok = [int(v) == self.world for v in agreed.tolist()]
+            if ok != [bool(f) for f in flags]:
+                self._note(f'a peer refused a collective form this rank accepted (local {flags}, agreed {ok})')
+            self.use_avg, self.use_scatter = ok
+        self.plain_only = self.backend == 'nccl' and not (self.use_avg and self.use_scatter)
+        self.forms_agreed = True
+
+    def _note(self, why: str):
+        import warnings
+        warnings.warn(f'GradSlabReducer: {why}; that form stays off for the whole run (all_reduce(SUM) + divide instead)',
+                      RuntimeWarning)
+
     # ---- one collective on one contiguous range -------------------------------------------------------------
     def _launch(self, lo: int, hi: int, scatter_q: int = 0):
-        """all-reduce [lo, hi) (scatter_q = 0) or reduce-scatter it in W pieces of scatter_q elements."""
+        """all-reduce [lo, hi) (scatter_q = 0) or reduce-scatter it in W pieces of scatter_q elements.  Exceptions
+        propagate: the forms were agreed in `_agree_forms`, and a failure here is rank-local by construction."""
         if hi <= lo:
             return
-        avg = self.backend == 'nccl'
+        avg = self.use_avg
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM  # gloo has no AVG: divide after the wait
         if self.stage is not None:
             buf = self.stage[lo:hi]
             buf.copy_(self.flat[lo:hi])  # fp32 -> wire dtype on the compute stream; the collective is ordered behind it
         else:
             buf = self.flat[lo:hi]
-        work = None
-        if scatter_q and avg and not self.plain_only:
+        if scatter_q and self.use_scatter:
             mine = buf[self.rank * scatter_q:(self.rank + 1) * scatter_q]
-            try:
-                work = dist.reduce_scatter_tensor(mine, buf, op=op, group=self.pg, async_op=True)
-                keep = (lo + self.rank * scatter_q, lo + (self.rank + 1) * scatter_q)
-            except (RuntimeError, ValueError, NotImplementedError) as e:
-                self._degrade(f'in-place reduce_scatter_tensor(AVG) refused by the backend ({type(e).__name__}: {e})')
-        if work is None:
-            if avg and self.plain_only:
-                avg, op = False, dist.ReduceOp.SUM
-            try:
-                work = dist.all_reduce(buf, op=op, group=self.pg, async_op=True)
-            except (RuntimeError, ValueError, NotImplementedError) as e:
-                if not avg:
-                    raise
-                self._degrade(f'all_reduce(AVG) refused by the backend ({type(e).__name__}: {e})')
-                avg = False
-                work = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            work = dist.reduce_scatter_tensor(mine, buf, op=op, group=self.pg, async_op=True)
+            keep = (lo + self.rank * scatter_q, lo + (self.rank + 1) * scatter_q)
+        else:
+            work = dist.all_reduce(buf, op=op, group=self.pg, async_op=True)
             keep = (lo, hi)
         self.wire_bytes += buf.numel() * buf.element_size()
         self.pending.append((work, keep, not avg))
-
-    def _degrade(self, why: str):
-        """The RCCL forms of the exchange (AVG reduction, in-place reduce-scatter on arena views) have never run on
-        hardware (no multi-GPU node in rounds 1-5).  An argument-level refusal by the backend -- raised BEFORE anything is
-        enqueued, on every rank alike -- switches this reducer to the plainest form (all_reduce SUM + divide, which the
-        gloo tests exercise) instead of killing the job; ownership / results are unchanged, only the wire bytes grow."""
-        if not self.plain_only:
-            self.plain_only = True
-            import warnings
-            warnings.warn(f'GradSlabReducer: {why}; continuing with all_reduce(SUM) + divide', RuntimeWarning)
 
     def reduce_range(self, name: str, lo: int, hi: int):
         if self.world == 1 or not self.enabled or hi <= lo:

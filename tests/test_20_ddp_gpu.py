@@ -93,6 +93,13 @@ def _worker(rank, world, port, q, backend='gloo'):
         dist.destroy_process_group()
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
 def _backends():
     return ['gloo'] + (['nccl'] if torch.cuda.is_available() and torch.cuda.device_count() >= 2 else [])
 
@@ -105,7 +112,7 @@ def test_two_rank_data_parallel(backend):
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29700 + (os.getpid() % 1000) + (7 if backend == 'nccl' else 0)
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, backend)) for r in range(2)]
     for p in procs:
         p.start()
@@ -138,7 +145,7 @@ def _rccl_forms_worker(port, q):
         r._launch(40000, 40000 + qq, scatter_q=qq)             # in-place reduce_scatter_tensor(AVG)
         r.finish()
         torch.cuda.synchronize()
-        assert not r.plain_only, 'RCCL refused a call form and the reducer degraded'
+        assert r.forms_agreed and r.use_avg and r.use_scatter and not r.plain_only, 'RCCL refused a call form at attach()'
         assert torch.equal(flat, ref) and r.wire_bytes == (40000 - 128 + qq) * 4
         rb = GradSlabReducer(wire_dtype=torch.bfloat16)         # the staging arena is only allocated for world > 1: give it one
         rb.attach(flat)
@@ -164,11 +171,13 @@ def _rccl_forms_worker(port, q):
 def test_rccl_call_forms_on_a_single_rank_group():
     """No multi-GPU node has been available in rounds 1-5, so RCCL had never executed a line of this repo's exchange.  A
     world-size-1 nccl group on the one GPU runs every collective FORM the path uses (see the worker) -- an argument-level
-    refusal (ReduceOp.AVG, in-place views, bf16) would show here instead of on the first 8-GPU run."""
+    refusal (ReduceOp.AVG, in-place views, bf16) would show here instead of on the first 8-GPU run.  What a single rank
+    CANNOT show: with world = 1 reduce-scatter / all-gather are near no-ops, so the in-place ALIASING semantics for world > 1
+    (output = a view of the input) remain unverified on RCCL; the gloo tests cover the ownership arithmetic only."""
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    p = ctx.Process(target=_rccl_forms_worker, args=(29900 + (os.getpid() % 90), q))
+    p = ctx.Process(target=_rccl_forms_worker, args=(_free_port(), q))
     p.start()
     res = q.get(timeout=240)
     p.join(60)
@@ -293,7 +302,7 @@ def test_zero1_matches_unsharded():
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29800 + (os.getpid() % 1000)
+    port = _free_port()
     procs = [ctx.Process(target=_zero_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()

@@ -343,6 +343,18 @@ def test_get_latest_ckpt_and_logger(tmp_path, capsys):
     assert path == os.path.join(str(d), '0000500.pt') and ck == {'step': 500}
     assert len(msgs) == 1 and '0002000.pt' in msgs[0]
     assert tr.list_ckpts(str(d))[0].endswith('0002000.pt') and len(tr.list_ckpts(str(d))) == 3
+    # a *.pt.tmp that is still being written (a previous incarnation inside save_ckpt_atomic) is left alone;
+    # only one that has been quiet for min_age_s is a leftover
+    fresh, old = d / '0003000.pt.tmp', d / '0000050.pt.tmp'
+    fresh.write_bytes(b'x')
+    old.write_bytes(b'x')
+    os.utime(str(old), (1.0e9, 1.0e9))
+    msgs = []
+    tr.remove_stale_tmp(str(d), log=msgs.append)
+    assert fresh.exists() and not old.exists() and (d / '0009999.pt.tmp').exists()
+    assert any('left alone' in m and '0003000' in m for m in msgs) and any('removed' in m and '0000050' in m for m in msgs)
+    tr.remove_stale_tmp(str(d), log=msgs.append, min_age_s=0.0)
+    assert not fresh.exists() and not (d / '0009999.pt.tmp').exists()
 
 
 def test_zero1_slab_ownership_tiles_every_slab():

@@ -75,13 +75,22 @@ def save_ckpt_atomic(obj, path):
         pass  # (file systems that cannot fsync a directory)
 
 
-def remove_stale_tmp(ckpt_dir, log=print):
-    """`<step>.pt.tmp` files are what a killed save leaves behind: never a checkpoint, only disk space."""
+def remove_stale_tmp(ckpt_dir, log=print, min_age_s=600.0):
+    """`<step>.pt.tmp` files are what a killed save leaves behind: never a checkpoint, only disk space.  Only
+    files that have not been written to for `min_age_s` go: during a preemption grace period, or on a lagging shared file
+    system, the PREVIOUS incarnation of the job may still be inside save_ckpt_atomic, and unlinking the file it is writing
+    would make its os.replace publish nothing."""
+    import time
     if os.path.isdir(ckpt_dir):
+        now = time.time()
         for f in os.listdir(ckpt_dir):
             if re.fullmatch(r'\d+\.pt\.tmp', f):
+                full = os.path.join(ckpt_dir, f)
                 try:
-                    os.remove(os.path.join(ckpt_dir, f))
+                    if now - os.path.getmtime(full) < min_age_s:
+                        log(f'left alone (written {now - os.path.getmtime(full):.0f} s ago, possibly a save in progress): {f}')
+                        continue
+                    os.remove(full)
                     log(f'removed the leftover of an interrupted save: {f}')
                 except OSError:
                     pass
