@@ -63,6 +63,7 @@ def parse():
     ap.add_argument('--no-kernel-events', action='store_true', help='skip the per-launch HIP events (roofline = null)')
     ap.add_argument('--cpu-batch', type=int, default=16)
     ap.add_argument('--no-sampler', action='store_true', help='skip the EDM sampler leg (BASELINE configs[4])')
+    ap.add_argument('--no-sampler-fp32', action='store_true', help='skip the fp32-faithful repetition of the sampler leg (~30 s)')
     ap.add_argument('--sampler-batch', type=int, default=64)
     ap.add_argument('--sampler-steps', type=int, default=50)
     ap.add_argument('--zero1', action='store_true', help='N > 1: ZeRO-1 (maskdit_amd.ShardedFusedAdam: reduce-scattered gradient '
@@ -453,6 +454,28 @@ def main():
             sampler = {'metric': f'EDM samples/sec {args.model} {args.sampler_steps}-step Heun cfg=1.5 bs={sb}', 'value': round(sb / te, 3),
                        'unit': 'samples/s', 'seconds': round(te, 3), 'net_evals': evals, 'finite': ok, 'hipgraph': True,
                        'model_tflops_per_s': round(sb * evals * 2 * 251.6e9 / te / 1e12, 1) if (args.model, R) == ('DiT-XL/2', 32) else None}
+            # ... and the same workload at the REFERENCE'S OWN PRECISION: sample.py:56 evaluates the network in fp32 (no
+            # autocast in generate.py); precision='fp32' = fp32 weights / activations / v_mfma_f32_32x32x2_f32 (157 TF peak)
+            if not args.no_sampler_fp32:
+                try:
+                    M.edm_sampler(ema, lat, lab, cfg_scale=1.5, num_steps=2, precision='fp32')  # capture + warm-up
+                    torch.cuda.synchronize()
+                    ts = time.perf_counter()
+                    z32 = M.edm_sampler(ema, lat, lab, cfg_scale=1.5, num_steps=args.sampler_steps, precision='fp32')
+                    torch.cuda.synchronize()
+                    t32 = time.perf_counter() - ts
+                    sampler['fp32_value'] = round(sb / t32, 3)
+                    sampler['fp32'] = {'seconds': round(t32, 3), 'finite': bool(torch.isfinite(z32).all()), 'hipgraph': True,
+                                       'arithmetic': 'exact fp32 (fp32 master weights, fp32 activations, v_mfma_f32_32x32x2_f32)',
+                                       'peak_tflops': 157.3,
+                                       'model_tflops_per_s': round(sb * evals * 2 * 251.6e9 / t32 / 1e12, 1) if (args.model, R) == ('DiT-XL/2', 32) else None,
+                                       'bf16_vs_fp32_rel_to_max': round(float((z - z32).abs().max() / z32.abs().max()), 6)}
+                    from maskdit_amd import sampler as _smp
+                    _smp.release_graphs()
+                    ema.engine().release_plans()
+                    torch.cuda.empty_cache()
+                except Exception as e:  # noqa: BLE001
+                    sampler['fp32'] = {'error': repr(e)}
             # the step that follows the sampler in generate.py (sample.py:248,273-284): VAE decode of the latents
             # (random-init decoder of the reference architecture; ~0.62 TFLOP per 256^2 image)
             try:

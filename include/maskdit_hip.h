@@ -25,7 +25,7 @@ typedef uint16_t mdt_bf16;
 const char* mdt_last_error(void);
 /* ABI revision of this header: a binding must refuse a library whose mdt_version() differs (a changed signature would
  * otherwise be called with the wrong argument list). */
-#define MDT_ABI_VERSION 3
+#define MDT_ABI_VERSION 4
 int mdt_version(void);
 /* Process-wide tuning knobs (benchmarking / A-B tests only; defaults are the product path).
  * "gemm_nt_variant": 0 = auto, 1 = force the 128x128-tile kernel, 2 = force the 256-row
@@ -253,6 +253,47 @@ int mdt_sampler_heun(const double* x_hat, double* x_next, const float* F, const 
 int mdt_sampler_advance(int32_t* step_idx, mdt_stream_t stream);
 /* classifier-free guidance combine on F = [cond; uncond] (models/maskdit.py:580-583), n = B*chw */
 int mdt_cfg_combine(const float* F, float cfg_scale, float* out, long n, mdt_stream_t stream);
+
+/* ---------------------------------------------------------------- fp32-faithful inference path ---- */
+
+/* The reference's sampler evaluates its network in fp32 (sample.py:56 `net(x_hat.float(), ...)`; generate.py has no
+ * autocast) and `train.py --no_amp` (train.py:39-46) runs fp32 too.  The entries below are that arithmetic on gfx950:
+ * exact fp32 operands from the fp32 master weights, fp32 activations, the fp32-input matrix instruction
+ * (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak).  csrc/f32path.hip. */
+enum mdt_f32_epilogue {
+  MDT_F32EPI_NONE = 0,     /* out = acc + bias                                                        */
+  MDT_F32EPI_GELU = 1,     /* out = gelu_tanh(acc + bias)          (timm Mlp act, models/maskdit.py:181) */
+  MDT_F32EPI_SILU = 2,     /* out = silu(acc + bias)               (TimestepEmbedder.mlp, :34-38)      */
+  MDT_F32EPI_GATE_RES = 3  /* out = res + gate[row / rows_per_sample] * (acc + bias)   (:190-191); gate NULL = 1 */
+};
+/* out[z][M,N] = A[z][M,K] * B[z]^T (+ bias[N]) with an fp32 epilogue; z = b * heads + h runs over `batch` problems whose
+ * operand bases are base + b * stride_b + h * stride_h (elements): nn.Linear (batch 1) and, with the packed qkv buffer,
+ * timm Attention's q k^T (B = k rows, N = K-contiguous) and p v (b_kmajor = 1: B is [K, N] row-major, the v rows).
+ * K % 4 == 0, 16-byte aligned operand rows / strides; M, N arbitrary. */
+typedef struct {
+  const float* A; long lda;
+  const float* B; long ldb; int b_kmajor;
+  int M, N, K;
+  const float* bias;
+  int epi;
+  float* out; long ldo;
+  const float* res; long ldres;
+  const float* gate; long gate_ld; int rows_per_sample;
+  int batch, heads; /* 0 = 1 */
+  long a_stride_b, a_stride_h, b_stride_b, b_stride_h, o_stride_b, o_stride_h;
+} mdt_gemm_f32_args;
+int mdt_gemm_f32(const mdt_gemm_f32_args* a, mdt_stream_t stream);
+/* s[r, :] = softmax(s[r, :n_valid] * scale), in place, columns >= n_valid set to 0 (timm Attention: softmax(q k^T * hd^-0.5)) */
+int mdt_softmax_rows_f32(float* s, long R, int n, int n_valid, float scale, mdt_stream_t stream);
+/* mdt_ln_modulate_fwd with an fp32 result (models/maskdit.py:19-20,177; eps 1e-6) */
+int mdt_ln_modulate_f32(const float* x, const float* shift, const float* scale, int mod_ld, int rows_per_sample,
+                        float* xn, int M, int D, mdt_stream_t stream);
+/* mdt_timestep_embed with an fp32 result (models/maskdit.py:41-60) */
+int mdt_timestep_embed_f32(const float* t, float* out, int ld, int B, int dim, mdt_stream_t stream);
+/* out = silu(in)  (the SiLU in front of every adaLN Linear, models/maskdit.py:183-186) */
+int mdt_silu_f32(const float* in, float* out, long n, mdt_stream_t stream);
+/* out[(b, j), :] = in[(b, j), :] + rows[j, :], j = row % T: `x + decoder_pos_embed` (models/maskdit.py:545); D % 4 == 0 */
+int mdt_add_rows_f32(const float* in, const float* rows, float* out, long n_rows, int T, int D, mdt_stream_t stream);
 
 /* ---------------------------------------------------------------- VAE decoder glue ------ */
 

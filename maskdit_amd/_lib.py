@@ -36,6 +36,16 @@ class GemmTNArgs(C.Structure):
                 ('C', vp), ('ldc', i32), ('n1_valid', i32), ('n2_valid', i32), ('splits', i32), ('colsum_a', vp)]
 
 
+class GemmF32Args(C.Structure):
+    _fields_ = [('A', vp), ('lda', i64), ('B', vp), ('ldb', i64), ('b_kmajor', i32), ('M', i32), ('N', i32), ('K', i32),
+                ('bias', vp), ('epi', i32), ('out', vp), ('ldo', i64), ('res', vp), ('ldres', i64), ('gate', vp),
+                ('gate_ld', i64), ('rows_per_sample', i32), ('batch', i32), ('heads', i32),
+                ('a_stride_b', i64), ('a_stride_h', i64), ('b_stride_b', i64), ('b_stride_h', i64),
+                ('o_stride_b', i64), ('o_stride_h', i64)]
+
+
+F32EPI_NONE, F32EPI_GELU, F32EPI_SILU, F32EPI_GATE_RES = range(4)
+
 # name -> argtypes (the trailing stream argument is added to every compute entry)
 _PROTOS = {
     'mdt_gemm_nt': [C.POINTER(GemmNTArgs)],
@@ -81,6 +91,12 @@ _PROTOS = {
     'mdt_vae_prologue': [vp, vp, vp, vp, i32, i32, f32],
     'mdt_vae_epilogue': [vp, i32, vp, i32, i32, i32],
     'mdt_lds_poison': [vp],
+    'mdt_gemm_f32': [C.POINTER(GemmF32Args)],
+    'mdt_softmax_rows_f32': [vp, i64, i32, i32, f32],
+    'mdt_ln_modulate_f32': [vp, vp, vp, i32, i32, vp, i32, i32],
+    'mdt_timestep_embed_f32': [vp, vp, i32, i32, i32],
+    'mdt_silu_f32': [vp, vp, i64],
+    'mdt_add_rows_f32': [vp, vp, vp, i64, i32, i32],
 }
 # entries without the trailing stream
 _PLAIN = {
@@ -97,7 +113,7 @@ _PLAIN = {
     'mdt_nt8o_stamps': [C.POINTER(C.c_uint64)],
 }
 EXPORTED = sorted(list(_PROTOS) + list(_PLAIN) + ['mdt_last_error', 'mdt_version'])
-ABI_VERSION = 3  # == MDT_ABI_VERSION of include/maskdit_hip.h (tests/test_capi_cpu.py compares the two)
+ABI_VERSION = 4  # == MDT_ABI_VERSION of include/maskdit_hip.h (tests/test_capi_cpu.py compares the two)
 
 
 class MaskDiTLibError(RuntimeError):

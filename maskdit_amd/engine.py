@@ -30,8 +30,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GATE_RES, EPI_GELU, EPI_SILU, GemmNTArgs,
-                   GemmTNArgs)
+from ._lib import (EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GATE_RES, EPI_GELU, EPI_SILU, F32EPI_GATE_RES,
+                   F32EPI_GELU, F32EPI_NONE, F32EPI_SILU, GemmF32Args, GemmNTArgs, GemmTNArgs)
 
 DEC_HIDDEN, DEC_DEPTH, DEC_HEADS = 512, 8, 16  # models/maskdit.py:310-312
 MODEL_CONFIGS = {  # models/maskdit.py:649-715  name -> (depth, hidden, patch, heads)
@@ -305,14 +305,19 @@ class Engine:
         self.shadows_dirty = False
 
     # ---- plans -------------------------------------------------------------------------
-    def plan(self, B: int, masked: bool, train: bool, L: Optional[int] = None) -> 'PassPlan':
+    def plan(self, B: int, masked: bool, train: bool, L: Optional[int] = None, precision: str = 'bf16') -> 'PassPlan':
         """Plans are keyed on the kept-token count ROUNDED UP to the 64-row tile: a mask-ratio schedule
         (train_utils/helper.py:9-27) changes the exact count nearly every step, but buffers and launch lists only
         depend on the padded count -- the exact one is a run-time argument of the four launches that read it
         (PassPlan.set_valid)."""
         global _PLAN_CLOCK
+        if precision not in ('bf16', 'fp32'):
+            raise ValueError(f"precision must be 'bf16' or 'fp32', got {precision!r}")
+        if precision == 'fp32' and (masked or train):
+            raise NotImplementedError('the fp32-faithful path covers inference (the sampler / eval forward: sample.py:56); '
+                                      'fp32 TRAINING (train.py --no_amp) is not provided')
         Lv = (L if L is not None else self.sp.T // 2) if masked else None
-        key = (B, masked, train, _rup(Lv, 64) if masked else None)
+        key = plan_key(B, masked, train, Lv, precision)
         pl = self._plans.pop(key, None)
         if pl is None:
             # LRU cache under a DEVICE-wide memory budget.  Round 2 dropped every training plan whenever another shape
@@ -324,7 +329,7 @@ class Engine:
             # until it fits (5 % of the device stays free for the caller's own tensors) or nothing is left to drop.
             while len(self._plans) >= 8:
                 _drop_plan(self, next(iter(self._plans)))
-            need = PassPlan.estimate_bytes(self.sp, B, masked, train, Lv)
+            need = PassPlan.estimate_bytes(self.sp, B, masked, train, Lv) * (2 if precision == 'fp32' else 1)
             # (a plan something else still refers to -- a pending backward, a captured sampler graph -- gives no memory back
             # when its cache entry goes: after two evictions in a row that freed nothing the loop stops instead of emptying
             # every engine's cache for no gain)
@@ -336,7 +341,7 @@ class Engine:
                 fruitless = fruitless + 1 if _device_available(self.device) <= before else 0
             while True:
                 try:
-                    pl = PassPlan(self, B, masked, train, Lv)
+                    pl = PassPlan(self, B, masked, train, Lv, precision)
                     break
                 except torch.cuda.OutOfMemoryError:
                     if not _evict_lru_plan(self.device):
@@ -355,6 +360,12 @@ class Engine:
 
 
 _PLAN_CLOCK = 0
+
+
+def plan_key(B: int, masked: bool, train: bool, Lv: Optional[int] = None, precision: str = 'bf16') -> tuple:
+    """Cache key of Engine.plan(): bf16 keys keep their round-1..5 form; an fp32 plan is another entry."""
+    key = (B, masked, train, _rup(Lv, 64) if masked else None)
+    return key if precision == 'bf16' else key + (precision,)
 
 
 def _device_total(device) -> int:
@@ -416,8 +427,9 @@ def _tn(A, lda, Bm, ldb, M, N1, N2, Cc, ldc, n1v=0, n2v=0, splits=0, colsum_a=0)
 class PassPlan:
     """Buffers + forward/backward launch lists for a fixed (batch, masked?, train?) shape."""
 
-    def __init__(self, eng: Engine, B: int, masked: bool, train: bool, L: Optional[int]):
+    def __init__(self, eng: Engine, B: int, masked: bool, train: bool, L: Optional[int], precision: str = 'bf16'):
         sp = eng.sp
+        self.precision = precision
         # the engine caches its plans, so a plan must not own its engine: Engine <-> PassPlan reference cycles kept
         # 20-240 GB of a dropped model alive until Python's cyclic collector happened to run (VERDICT r3 weak #5)
         self._eng_ref = weakref.ref(eng)
@@ -443,7 +455,10 @@ class PassPlan:
         self.fwd = Plan()
         self.bwd = Plan()
         self.gen = 0  # forward generation: the saved activations belong to the LAST forward through this plan
-        self._build()
+        if precision == 'fp32':
+            self._build_f32()
+        else:
+            self._build()
 
     @property
     def eng(self) -> Engine:
@@ -662,6 +677,120 @@ class PassPlan:
         g.add('mdt_colsum_bf16', dh1.data_ptr(), D, Gf('model.t_embedder.mlp.0.bias'), B, D)
         self._slab('misc')
 
+    # ---- the fp32-faithful inference plan (csrc/f32path.hip) ------------------------------------------------------
+    def _build_f32(self):
+        """The eval forward in EXACT fp32 -- what the reference's sampler runs (sample.py:56 `net(x_hat.float(), ...)`, no
+        autocast in generate.py): fp32 master weights straight from the parameter arena (no bf16 shadow is read), fp32
+        activations, fp32-input MFMA GEMMs (mdt_gemm_f32), attention as q k^T -> row softmax -> p v over the packed qkv
+        buffer.  Same graph as _build (DiT.forward, models/maskdit.py:511-557, unmasked), same input / output buffers
+        ('xin', 'coef', 'labels', 'F'), so the sampler and EDMPrecond.forward drive either plan the same way."""
+        eng, sp, lay = self.eng, self.eng.sp, self.eng.lay
+        B, T, D, Dd = self.B, self.T, sp.D, sp.Dd
+        NM = sp.n_mod
+        assert not self.masked and not self.train
+        if sp.num_classes % 4:
+            raise NotImplementedError('fp32 path: num_classes must be a multiple of 4 (16-byte label rows)')
+        if B * max(sp.heads, sp.dheads) > 65535:
+            raise NotImplementedError('fp32 path: batch * heads must not exceed 65535 (one grid row per (sample, head))')
+        Pp = eng.P.data_ptr()
+
+        def Pf(name):
+            return Pp + 4 * lay.off[name]
+
+        f = self.fwd
+        xin = self.f32('xin', B, sp.C, sp.R, sp.R)
+        coef = self.f32('coef', 8, B)
+        cn = coef[3]
+        self.buf['c_noise'] = cn
+        lab = self.f32('labels', B, sp.num_classes)
+        Fx = self.f32('F', B, sp.C, sp.R, sp.R)
+        # ---------------- conditioning path (TimestepEmbedder :34-60, LabelEmbedder :75, SiLU + adaLN Linears :183-186)
+        temb, a1 = self.f32('temb', B, 256), self.f32('a1', B, D)
+        c_t, c, sc = self.f32('c_t', B, D), self.f32('c', B, D), self.f32('sc', B, D)
+        mod = self.f32('mod', B, NM)
+        f.add('mdt_timestep_embed_f32', cn.data_ptr(), temb.data_ptr(), 256, B, 256)
+        self._g32(temb, 256, Pf('model.t_embedder.mlp.0.weight'), 256, B, D, 256, a1, D, bias=Pf('model.t_embedder.mlp.0.bias'),
+                  epi=F32EPI_SILU)
+        self._g32(a1, D, Pf('model.t_embedder.mlp.2.weight'), D, B, D, D, c_t, D, bias=Pf('model.t_embedder.mlp.2.bias'))
+        # c = t_emb + y @ table^T (the one-hot / zero / soft label row times the embedding table)
+        self._g32(lab, sp.num_classes, Pf('model.y_embedder.embedding_table.weight'), sp.num_classes, B, D, sp.num_classes, c, D,
+                  epi=F32EPI_GATE_RES, res=c_t, ldres=D, rps=1)
+        f.add('mdt_silu_f32', c.data_ptr(), sc.data_ptr(), B * D)
+        self._g32(sc, D, Pp + 4 * lay.ada_w, D, B, NM, D, mod, NM, bias=Pp + 4 * lay.ada_b)
+        # ---------------- encoder (all T tokens: masking applies in train mode only, models/maskdit.py:482,539) ---------
+        Me = B * T
+        x = self.f32('x_e0', Me, D)
+        f.add('mdt_patch_embed_fwd', xin.data_ptr(), None, Pf('model.x_embedder.proj.weight'), Pf('model.x_embedder.proj.bias'),
+              eng.pos.data_ptr(), None, 2 * T, x.data_ptr(), B, sp.C, sp.R, sp.patch, T, D)
+        for i in range(sp.depth):
+            x = self._block_fwd_f32(f'model.blocks.{i}', 'e', i, x, mod, sp.mod_off('enc', i), D, sp.heads, T, Me)
+        self.marks = {'enc_fwd_end': len(f.calls)}
+        # ---------------- DecoderLayer (:195-213) + decoder_pos_embed (:545) -------------------------------------------
+        odl = sp.mod_off('dl')
+        xnd, xdec = self.f32('xn_e', Me, D), self.f32('xdec', Me, Dd)
+        f.add('mdt_ln_modulate_f32', x.data_ptr(), mod.data_ptr() + 4 * odl, mod.data_ptr() + 4 * (odl + D), NM, T, xnd.data_ptr(), Me, D)
+        self._g32(xnd, D, Pf('model.decoder_layer.linear.weight'), D, Me, Dd, D, xdec, Dd, bias=Pf('model.decoder_layer.linear.bias'))
+        x = self.f32('x_d0', Me, Dd)
+        f.add('mdt_add_rows_f32', xdec.data_ptr(), eng.dpos.data_ptr(), x.data_ptr(), Me, T, Dd)
+        for i in range(sp.ddepth):
+            x = self._block_fwd_f32(f'model.decoder_blocks.{i}', 'd', i, x, mod, sp.mod_off('dec', i), Dd, sp.dheads, T, Me)
+        ofin = sp.mod_off('fin')
+        st_f = self.f32('st_f', Me, 2)
+        f.add('mdt_final_fwd', x.data_ptr(), mod.data_ptr() + 4 * ofin, mod.data_ptr() + 4 * (ofin + Dd), NM,
+              Pf('model.final_layer.linear.weight'), Pf('model.final_layer.linear.bias'), Fx.data_ptr(), st_f.data_ptr(),
+              B, T, Dd, sp.C, sp.patch)
+
+    def _g32(self, A, lda, Bw, ldb, M, N, K, out, ldo, bias=0, epi=F32EPI_NONE, res=None, ldres=0, gate=0, gate_ld=0, rps=1,
+             b_kmajor=0, batch=0, heads=0, a_s=(0, 0), b_s=(0, 0), o_s=(0, 0)):
+        """One mdt_gemm_f32 launch; A / out / res are tensors or raw addresses, Bw / bias / gate raw addresses."""
+        ptr = lambda t: t if isinstance(t, int) else t.data_ptr()  # noqa: E731
+        a = GemmF32Args()
+        a.A, a.lda, a.B, a.ldb, a.b_kmajor = ptr(A), lda, Bw, ldb, b_kmajor
+        a.M, a.N, a.K = M, N, K
+        a.bias, a.epi = bias or None, epi
+        a.out, a.ldo = ptr(out), ldo
+        a.res, a.ldres = (ptr(res) if res is not None else None), ldres
+        a.gate, a.gate_ld, a.rows_per_sample = gate or None, gate_ld, rps
+        a.batch, a.heads = batch, heads
+        a.a_stride_b, a.a_stride_h = a_s
+        a.b_stride_b, a.b_stride_h = b_s
+        a.o_stride_b, a.o_stride_h = o_s
+        self.fwd.add('mdt_gemm_f32', C.byref(self._k(a)))
+
+    def _block_fwd_f32(self, prefix, tag, i, x_in, mod, moff, W, heads, rows, M):
+        """DiTBlock.forward (models/maskdit.py:188-192) in fp32; all blocks of a stack share one buffer set."""
+        eng, lay, f = self.eng, self.eng.lay, self.fwd
+        NM = eng.sp.n_mod
+        hd = W // heads
+        B = self.B
+        Pp = eng.P.data_ptr()
+        Pf = lambda n: Pp + 4 * lay.off[f'{prefix}.{n}']  # noqa: E731
+        mp = mod.data_ptr()
+        sh1, sc1, g1, sh2, sc2, g2 = (mp + 4 * (moff + k * W) for k in range(6))
+        xn = self.f32(f'xn_{tag}', M, W)
+        qkv = self.f32(f'qkv_{tag}', M, 3 * W)
+        S = self.f32(f'scores_{tag}', B * heads * rows, rows)
+        ao = self.f32(f'ao_{tag}', M, W)
+        xmid = self.f32(f'xmid_{tag}', M, W)
+        h = self.f32(f'h_{tag}', M, 4 * W)
+        xout = self.f32(f'x_{tag}pp{(i + 1) % 2}', M, W)
+        f.add('mdt_ln_modulate_f32', x_in.data_ptr(), sh1, sc1, NM, rows, xn.data_ptr(), M, W)
+        self._g32(xn, W, Pf('attn.qkv.weight'), W, M, 3 * W, W, qkv, 3 * W, bias=Pf('attn.qkv.bias'))
+        # timm Attention: softmax(q k^T * hd^-0.5) v per (sample, head) on the packed [M, (3, heads, hd)] buffer
+        q0 = qkv.data_ptr()
+        self._g32(q0, 3 * W, q0 + 4 * W, 3 * W, rows, rows, hd, S, rows, batch=B * heads, heads=heads,
+                  a_s=(rows * 3 * W, hd), b_s=(rows * 3 * W, hd), o_s=(heads * rows * rows, rows * rows))
+        f.add('mdt_softmax_rows_f32', S.data_ptr(), B * heads * rows, rows, rows, float(hd) ** -0.5)
+        self._g32(S, rows, q0 + 8 * W, 3 * W, rows, hd, rows, ao, W, b_kmajor=1, batch=B * heads, heads=heads,
+                  a_s=(heads * rows * rows, rows * rows), b_s=(rows * 3 * W, hd), o_s=(rows * W, hd))
+        self._g32(ao, W, Pf('attn.proj.weight'), W, M, W, W, xmid, W, bias=Pf('attn.proj.bias'), epi=F32EPI_GATE_RES,
+                  res=x_in, ldres=W, gate=g1, gate_ld=NM, rps=rows)
+        f.add('mdt_ln_modulate_f32', xmid.data_ptr(), sh2, sc2, NM, rows, xn.data_ptr(), M, W)
+        self._g32(xn, W, Pf('mlp.fc1.weight'), W, M, 4 * W, W, h, 4 * W, bias=Pf('mlp.fc1.bias'), epi=F32EPI_GELU)
+        self._g32(h, 4 * W, Pf('mlp.fc2.weight'), 4 * W, M, W, 4 * W, xout, W, bias=Pf('mlp.fc2.bias'), epi=F32EPI_GATE_RES,
+                  res=xmid, ldres=W, gate=g2, gate_ld=NM, rps=rows)
+        return xout
+
     def _k(self, obj):
         self.fwd.keep.append(obj)
         return obj
@@ -787,7 +916,7 @@ class PassPlan:
 
     # ---- execution ---------------------------------------------------------------------------
     def run_forward(self) -> int:
-        if self.eng.shadows_dirty:
+        if self.eng.shadows_dirty and self.precision != 'fp32':  # (an fp32 plan reads the master arena itself)
             self.eng.refresh_shadows()
         self.gen += 1
         self.fwd.run(torch.cuda.current_stream().cuda_stream)

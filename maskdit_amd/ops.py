@@ -8,8 +8,8 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GATE_RES, EPI_GELU, EPI_SILU, GemmNTArgs,  # noqa: F401
-                   GemmTNArgs, call)
+from ._lib import (EPI_BF16, EPI_DGELU, EPI_DSILU, EPI_F32, EPI_GATE_RES, EPI_GELU, EPI_SILU, F32EPI_GATE_RES,  # noqa: F401
+                   F32EPI_GELU, F32EPI_NONE, F32EPI_SILU, GemmF32Args, GemmNTArgs, GemmTNArgs, call)
 
 
 def stream_ptr() -> int:
@@ -118,3 +118,47 @@ def mask_sort(noise, len_keep):
     ids32 = torch.empty(B, 2 * T, device=dev, dtype=torch.int32)
     call('mdt_mask_sort', p(noise), B, T, len_keep, p(ids_shuffle), p(ids_restore), p(mask), p(ids32), stream_ptr())
     return ids_shuffle, ids_restore, mask, ids32
+
+
+# ---- fp32-faithful inference path (csrc/f32path.hip) ----------------------------------------------------------------
+def gemm_f32(A, Bw, out, M, N, K, lda=None, ldb=None, ldo=None, bias=None, epi=F32EPI_NONE, res=None, gate=None, gate_ld=0,
+             rows_per_sample=1, b_kmajor=False, batch=0, heads=0, a_strides=(0, 0), b_strides=(0, 0), o_strides=(0, 0),
+             a_off=0, b_off=0, o_off=0):
+    """out[z] = A[z][M,K] @ B[z]^T (+ bias) in exact fp32 (mdt_gemm_f32); *_off = element offsets into the tensors."""
+    for t, nm in ((A, 'A'), (Bw, 'B'), (out, 'out')):
+        if t.dtype != torch.float32 or not t.is_cuda:
+            raise ValueError(f'{nm}: expected a CUDA float32 tensor')
+    a = GemmF32Args()
+    a.A, a.lda = A.data_ptr() + 4 * a_off, (A.stride(0) if lda is None else lda)
+    a.B, a.ldb, a.b_kmajor = Bw.data_ptr() + 4 * b_off, (Bw.stride(0) if ldb is None else ldb), int(b_kmajor)
+    a.M, a.N, a.K = M, N, K
+    a.bias, a.epi = p(bias), epi
+    a.out, a.ldo = out.data_ptr() + 4 * o_off, (out.stride(0) if ldo is None else ldo)
+    a.res, a.ldres = p(res), (res.stride(0) if res is not None else 0)
+    a.gate, a.gate_ld, a.rows_per_sample = p(gate), gate_ld, rows_per_sample
+    a.batch, a.heads = batch, heads
+    a.a_stride_b, a.a_stride_h = a_strides
+    a.b_stride_b, a.b_stride_h = b_strides
+    a.o_stride_b, a.o_stride_h = o_strides
+    call('mdt_gemm_f32', C.byref(a), stream_ptr())
+    return out
+
+
+def attention_f32(qkv, B, L, H, hd):
+    """timm Attention's softmax(q k^T hd^-0.5) v on a packed fp32 [B*L, 3*H*hd] buffer, as the fp32 plans run it."""
+    W = H * hd
+    S = torch.empty(B * H * L, L, device=qkv.device, dtype=torch.float32)
+    o = torch.empty(B * L, W, device=qkv.device, dtype=torch.float32)
+    gemm_f32(qkv, qkv, S, L, L, hd, lda=3 * W, ldb=3 * W, ldo=L, batch=B * H, heads=H, a_strides=(L * 3 * W, hd),
+             b_strides=(L * 3 * W, hd), o_strides=(H * L * L, L * L), b_off=W)
+    call('mdt_softmax_rows_f32', p(S), B * H * L, L, L, float(hd) ** -0.5, stream_ptr())
+    gemm_f32(S, qkv, o, L, hd, L, lda=L, ldb=3 * W, ldo=W, b_kmajor=True, batch=B * H, heads=H, a_strides=(H * L * L, L * L),
+             b_strides=(L * 3 * W, hd), o_strides=(L * W, hd), b_off=2 * W)
+    return o
+
+
+def ln_modulate_f32(x, shift, scale, mod_ld, rows_per_sample):
+    M, D = x.shape
+    xn = torch.empty(M, D, device=x.device, dtype=torch.float32)
+    call('mdt_ln_modulate_f32', p(x), p(shift), p(scale), mod_ld, rows_per_sample, p(xn), M, D, stream_ptr())
+    return xn

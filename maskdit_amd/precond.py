@@ -215,6 +215,10 @@ class EDMPrecond(nn.Module):
         self._seen_version = -1
         self._plist = None
         self._grad_items = None  # (gradient arena, [(parameter, its arena view)]) -- see _prepare_grad_arena
+        # arithmetic of INFERENCE evaluations (no-grad forward, forward_with_cfg, edm_sampler): 'bf16' = the training
+        # kernels (bf16 MFMA operands, fp32 residual stream -- the reference under autocast); 'fp32' = exact fp32 throughout
+        # (csrc/f32path.hip), what the reference's own sampler runs (sample.py:56, no autocast in generate.py).
+        self.eval_precision = 'bf16'
 
     # ---- engine binding ------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
@@ -288,6 +292,13 @@ class EDMPrecond(nn.Module):
 
     def round_sigma(self, sigma):
         return torch.as_tensor(sigma)
+
+    def set_eval_precision(self, precision: str):
+        """'bf16' (default) or 'fp32' (the reference sampler's own arithmetic; ~1/8 of the bf16 throughput)."""
+        if precision not in ('bf16', 'fp32'):
+            raise ValueError(f"precision must be 'bf16' or 'fp32', got {precision!r}")
+        self.eval_precision = precision
+        return self
 
     # ---- gradient plumbing ---------------------------------------------------------------
     def _prepare_grad_arena(self):
@@ -393,7 +404,8 @@ class _NetFn(torch.autograd.Function):
         B = x.shape[0]
         chw = sp.C * sp.R * sp.R
         masked = ids32 is not None
-        pl = eng.plan(B, masked, bool(need_grad), L)
+        prec = net.eval_precision if not (need_grad or masked) else 'bf16'  # training / masked forwards: bf16 kernels only
+        pl = eng.plan(B, masked, bool(need_grad), L, prec)
         st = _stream()
         coef = pl.buf['coef']
         call('mdt_precond_coef', sigma.data_ptr(), coef.data_ptr(), B, float(net.sigma_data), st)
@@ -430,7 +442,7 @@ def _run_cfg(net: EDMPrecond, x, sigma, labels, cfg_scale: float):
     B = x.shape[0]
     chw = sp.C * sp.R * sp.R
     st = _stream()
-    pl = eng.plan(2 * B, False, False, None)
+    pl = eng.plan(2 * B, False, False, None, net.eval_precision)
     # plan-side coefficients (c_noise feeds the timestep embedder) are laid out for 2B rows;
     # the input scaling / output blend act on the B real samples with their own table
     sig2 = torch.cat([sigma, sigma])

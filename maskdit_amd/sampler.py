@@ -22,6 +22,7 @@ import torch
 
 from . import _lib
 from ._lib import call
+from .engine import plan_key
 from .loss import unwrap_model
 from .precond import EDMPrecond
 
@@ -36,7 +37,7 @@ def edm_t_steps(num_steps, sigma_min, sigma_max, rho, device) -> torch.Tensor:
 class _GraphedHeun:
     """Captured graphs + persistent state buffers for one (net, batch, cfg?) shape."""
 
-    def __init__(self, net: EDMPrecond, B: int, use_cfg: bool, max_steps: int = 1024):
+    def __init__(self, net: EDMPrecond, B: int, use_cfg: bool, precision: str = 'bf16', max_steps: int = 1024):
         # neither the network nor its engine is OWNED by the graph cache (a module-level dict): a cached graph must not
         # keep a deleted model's arenas and plans alive
         self.B, self.use_cfg = B, use_cfg
@@ -46,7 +47,8 @@ class _GraphedHeun:
         self.chw = sp.C * sp.R * sp.R
         self.dup = 2 if use_cfg else 1
         self._eng_ref = weakref.ref(net.engine())
-        self.pl = self.eng.plan(B * self.dup, False, False, None)
+        self.precision = precision
+        self.pl = self.eng.plan(B * self.dup, False, False, None, precision)
         f64 = dict(device=dev, dtype=torch.float64)
         self.x_hat = torch.zeros(B, self.chw, **f64)
         self.x_next = torch.zeros(B, self.chw, **f64)
@@ -86,7 +88,7 @@ class _GraphedHeun:
     def capture(self, cfg_scale: float):
         L = _lib.lib()
         self.destroy()
-        if self.eng.shadows_dirty:
+        if self.eng.shadows_dirty and self.precision != 'fp32':
             self.eng.refresh_shadows()
         torch.cuda.synchronize()
         graphs = []
@@ -118,7 +120,7 @@ class _GraphedHeun:
             pass
 
 
-_CACHE: Dict[Tuple[int, int, bool], _GraphedHeun] = {}
+_CACHE: Dict[Tuple[int, int, bool, str], _GraphedHeun] = {}
 
 
 def release_graphs():
@@ -127,15 +129,15 @@ def release_graphs():
         _CACHE.popitem()[1].destroy()
 
 
-def _graphed(net: EDMPrecond, B: int, use_cfg: bool) -> _GraphedHeun:
+def _graphed(net: EDMPrecond, B: int, use_cfg: bool, precision: str = 'bf16') -> _GraphedHeun:
     for k in [k for k, v in _CACHE.items() if v.eng is None]:  # graphs of models that no longer exist
         _CACHE.pop(k).destroy()
-    key = (id(net.engine()), B, use_cfg)
+    key = (id(net.engine()), B, use_cfg, precision)
     g = _CACHE.get(key)
-    if g is None or g.eng is not net.engine() or g.pl is not net.engine()._plans.get((B * g.dup, False, False, None)):
+    if g is None or g.eng is not net.engine() or g.pl is not net.engine()._plans.get(plan_key(B * g.dup, False, False, None, precision)):
         if len(_CACHE) >= 4:
             _CACHE.pop(next(iter(_CACHE))).destroy()
-        g = _GraphedHeun(net, B, use_cfg)
+        g = _GraphedHeun(net, B, use_cfg, precision)
         _CACHE[key] = g
 
         def dropped(key=key, ref=weakref.ref(g)):  # the plan cache evicted the plan this graph replays
@@ -168,8 +170,13 @@ def _churn_steps(net, x, t_steps, class_labels, cfg_scale, randn_like, num_steps
 
 @torch.no_grad()
 def edm_sampler(net, latents, class_labels=None, cfg_scale=None, feat=None, randn_like=torch.randn_like, num_steps=18,
-                sigma_min=0.002, sigma_max=80, rho=7, S_churn=0, S_min=0, S_max=float('inf'), S_noise=1, use_graph=True):
-    """Same signature and result (fp64 [N, C, H, W]) as sample.py:30-66."""
+                sigma_min=0.002, sigma_max=80, rho=7, S_churn=0, S_min=0, S_max=float('inf'), S_noise=1, use_graph=True,
+                precision=None):
+    """Same signature and result (fp64 [N, C, H, W]) as sample.py:30-66.  `precision` (an addition): arithmetic of the
+    network evaluations -- 'bf16' (bf16 MFMA operands, fp32 residual stream: the training kernels; 18-19 samples/s for XL/2,
+    drift 7e-4 of the latent range against the reference's fp32 network after 50 steps) or 'fp32' (exact fp32 weights,
+    activations and matrix instructions: what sample.py:56 itself runs, agreeing with the reference fixture to fp32
+    rounding); None = the network's `eval_precision` (default 'bf16')."""
     raw = unwrap_model(net)
     if not isinstance(raw, EDMPrecond):
         raise TypeError(f'maskdit_amd.edm_sampler expects a maskdit_amd EDMPrecond, got {type(raw).__name__}')
@@ -185,19 +192,28 @@ def edm_sampler(net, latents, class_labels=None, cfg_scale=None, feat=None, rand
     B = latents.shape[0]
     labels = raw._labels(class_labels, B, latents.device)
     x_next = latents.to(torch.float64) * t_steps[0]  # sample.py:46
+    precision = raw.eval_precision if precision is None else precision
+    if precision not in ('bf16', 'fp32'):
+        raise ValueError(f"precision must be 'bf16' or 'fp32', got {precision!r}")
     if S_churn != 0:
         # stochastic churn (sample.py:51-53; no shipped config uses it): every network evaluation is the HIP forward
         # plan, the fp64 state algebra of the step -- which now carries a per-step noise level t_hat != t_i -- is torch
-        return _churn_steps(raw, x_next, t_steps, class_labels, cfg_scale, randn_like, num_steps, S_churn, S_min, S_max, S_noise)
+        prev, raw.eval_precision = raw.eval_precision, precision
+        try:
+            return _churn_steps(raw, x_next, t_steps, class_labels, cfg_scale, randn_like, num_steps, S_churn, S_min, S_max, S_noise)
+        finally:
+            raw.eval_precision = prev
 
     use_cfg = cfg_scale is not None
-    g = _graphed(raw, B, use_cfg)
+    g = _graphed(raw, B, use_cfg, precision)
     if num_steps + 1 > g.t_steps.numel():
         raise ValueError('num_steps exceeds the captured schedule capacity (1024)')
     s = float(cfg_scale) if use_cfg else 0.0
-    if use_graph and (g.graph_full is None or g.captured_cfg != s or raw.engine().shadows_dirty):
+    # (an fp32 plan reads the fp32 master arena: stale bf16 shadows do not concern its captured graphs)
+    stale = raw.engine().shadows_dirty and precision != 'fp32'
+    if use_graph and (g.graph_full is None or g.captured_cfg != s or stale):
         g.capture(s)
-    if not use_graph and raw.engine().shadows_dirty:
+    if not use_graph and stale:
         raw.engine().refresh_shadows()
     L = _lib.lib()
     cur = torch.cuda.current_stream()

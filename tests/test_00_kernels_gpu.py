@@ -1024,3 +1024,72 @@ def test_graph_capture_replay():
     s.synchronize()
     assert float(a[0]) == 9.0 and float(o[0]) == 7.0
     _lib.check(L.mdt_graph_destroy(g), 'destroy')
+
+
+# ------------------------------------------------------------------------------------------
+# fp32-faithful inference path (csrc/f32path.hip).  References are torch fp64 on the same fp32
+# inputs; the bound is fp32 rounding of a K-term sum (the kernels accumulate in fp32 in a different order than any
+# other fp32 implementation would), stated relative to the output's largest magnitude.
+def _f32_close(got, ref64, tol, what):
+    err = (got.double() - ref64).abs().max().item() / (ref64.abs().max().item() + 1e-30)
+    assert err <= tol, f'{what}: rel-to-max err {err:.3e} > {tol:.1e}'
+    return err
+
+
+@pytest.mark.parametrize('M,N,K,epi', [(300, 200, 256, 'NONE'), (128, 1152, 1152, 'GELU'), (257, 96, 1000, 'SILU'),
+                                        (512, 384, 1536, 'GATE_RES'), (64, 3456, 72, 'NONE'), (130, 40, 36, 'GATE_RES'),
+                                        (2048, 1152, 4608, 'GATE_RES'), (33, 20, 4, 'NONE')])
+def test_gemm_f32_vs_fp64(M, N, K, epi):
+    """mdt_gemm_f32: every epilogue, ragged M / N / K tiles (K only needs % 4), the three column-tile widths."""
+    torch.manual_seed(7)
+    A = torch.randn(M, K, device=DEV)
+    W = torch.randn(N, K, device=DEV) * K ** -0.5
+    b = torch.randn(N, device=DEV)
+    out = torch.full((M, N), float('nan'), device=DEV)
+    kw = dict(bias=b, epi=getattr(ops, 'F32EPI_' + epi))
+    ref = A.double() @ W.double().t() + b.double()
+    if epi == 'GELU':
+        ref = F.gelu(ref, approximate='tanh')
+    elif epi == 'SILU':
+        ref = F.silu(ref)
+    elif epi == 'GATE_RES':
+        rps = 64 if M % 64 == 0 else 1
+        res = torch.randn(M, N, device=DEV)
+        gate = torch.randn(M // rps, N + 8, device=DEV)
+        kw.update(res=res, gate=gate, gate_ld=N + 8, rows_per_sample=rps)
+        ref = res.double() + gate[:, :N].double().repeat_interleave(rps, 0) * ref
+    ops.gemm_f32(A, W, out, M, N, K, **kw)
+    e = _f32_close(out, ref, 2e-6, f'gemm_f32 {M}x{N}x{K} {epi}')
+    print(f'gemm_f32 {M}x{N}x{K} {epi}: rel-to-max err {e:.2e}')
+    # k-major B (the p v form): the same product from the transposed weight
+    if N % 4 == 0 and epi == 'NONE':
+        out2 = torch.full((M, N), float('nan'), device=DEV)
+        Wt = W.t().contiguous()
+        ops.gemm_f32(A, Wt, out2, M, N, K, bias=b, b_kmajor=True)
+        _f32_close(out2, ref, 2e-6, f'gemm_f32 k-major {M}x{N}x{K}')
+
+
+@pytest.mark.parametrize('B_,L,H,hd', [(3, 256, 16, 72), (2, 256, 16, 32), (2, 64, 6, 64), (1, 1024, 2, 32), (2, 128, 3, 80)])
+def test_attention_f32_vs_fp64(B_, L, H, hd):
+    """The fp32 plans' attention (batched q k^T -> in-place row softmax -> batched p v on the packed qkv buffer)."""
+    torch.manual_seed(9)
+    W = H * hd
+    qkv = torch.randn(B_ * L, 3 * W, device=DEV)
+    o = ops.attention_f32(qkv, B_, L, H, hd)
+    q, k, v = qkv.double().view(B_, L, 3, H, hd).permute(2, 0, 3, 1, 4)
+    ref = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v
+    ref = ref.permute(0, 2, 1, 3).reshape(B_ * L, W)
+    e = _f32_close(o, ref, 2e-6, f'attention_f32 B{B_} L{L} H{H} hd{hd}')
+    print(f'attention_f32 B{B_} L{L} H{H} hd{hd}: rel-to-max err {e:.2e}')
+
+
+@pytest.mark.parametrize('B_,L,D', [(3, 128, 1152), (2, 64, 512), (5, 16, 384), (3, 16, 1280)])
+def test_ln_modulate_f32_vs_fp64(B_, L, D):
+    torch.manual_seed(4)
+    M = B_ * L
+    x = torch.randn(M, D, device=DEV) * 2 + 0.5
+    mod = torch.randn(B_, 3 * D, device=DEV) * 0.5
+    got = ops.ln_modulate_f32(x, mod[:, :D], mod[:, 2 * D:], 3 * D, L)
+    xd = x.double()
+    ref = F.layer_norm(xd, (D,), eps=1e-6).reshape(B_, L, D) * (1 + mod[:, None, 2 * D:].double()) + mod[:, None, :D].double()
+    _f32_close(got, ref.reshape(M, D), 2e-6, 'ln_modulate_f32')

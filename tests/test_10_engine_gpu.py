@@ -211,6 +211,82 @@ def test_xl2_sampler_50_steps_vs_reference_fixture(golden_dir):
     assert e <= 3e-3 and rms <= 3e-3  # measured 7.1e-4 / 8.0e-4 on MI355X (99 bf16 network evaluations)
 
 
+TOL_F32 = 5e-6  # fp32-faithful path vs the reference's fp32 network: summation order only (measured on MI355X: 1.2e-7 after 99 XL/2 evaluations, <= 1.5e-6 on the S/2 fixtures)
+
+
+def test_xl2_sampler_50_steps_vs_reference_fixture_fp32(golden_dir):
+    """BASELINE configs[4] at the REFERENCE'S OWN PRECISION: sample.py:56 evaluates the network in
+    fp32 (`net(x_hat.float(), ...)`, no autocast in generate.py).  `precision='fp32'` runs the exact-fp32 plan
+    (csrc/f32path.hip: fp32 master weights, fp32 activations, v_mfma_f32_32x32x2_f32) through the same two captured graphs;
+    after 99 network evaluations it must agree with the reference's edm_sampler output to fp32 rounding -- two orders of
+    magnitude below the bf16 network's drift (7e-4 in the test above)."""
+    g = _load(golden_dir, 'xl2_sampler.npz')
+    cfg, P, net = _build('DiT-XL/2', 32, int(g['seed']), train=False)
+    labels = torch.eye(1000)[torch.from_numpy(g['cls'])].to(DEV)
+    lat = torch.from_numpy(g['latents']).to(DEV)
+    z = M.edm_sampler(net, lat, labels, cfg_scale=float(g['cfg_scale']), num_steps=int(g['num_steps']), precision='fp32')
+    ref = torch.from_numpy(g['z'])
+    e = _relmax(z, ref)
+    rms = ((z.cpu() - ref).norm() / ref.norm()).item()
+    print(f'XL/2 50-step sampler (fp32 net) vs reference (fp32 net): rel-to-max err {e:.3e}, rel L2 err {rms:.3e}')
+    assert z.dtype == torch.float64 and bool(torch.isfinite(z).all())
+    assert e <= TOL_F32 and rms <= TOL_F32
+    # the bf16 plan of the same network is untouched by the fp32 one (separate plan-cache entries and graphs)
+    zb = M.edm_sampler(net, lat, labels, cfg_scale=float(g['cfg_scale']), num_steps=int(g['num_steps']))
+    assert 1e-5 < _relmax(zb, ref) <= 3e-3
+
+
+def test_eval_forward_cfg_and_sampler_fp32_vs_oracle(golden_dir):
+    """The fp32-faithful plan behind every inference call form: plain eval forward, forward_with_cfg, the graph and the
+    direct-launch sampler, the churn branch -- each against the fp32 oracle / reference fixture at TOL_F32."""
+    cfg, P, net = _build('DiT-S/2', 32, seed=5, train=False)
+    net.set_eval_precision('fp32')
+    gcpu = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 4, 32, 32, generator=gcpu) * 3
+    sigma = torch.tensor([0.3, 2.0, 40.0])
+    y = torch.zeros(3, 1000)
+    y[torch.arange(3), torch.tensor([1, 500, 999])] = 1
+    with torch.no_grad():
+        D = net(x.to(DEV), sigma.to(DEV), y.to(DEV))['x']
+        ref = O.precond_forward(P, cfg, x, sigma, y, training=False)
+        e1 = _relmax(D, ref)
+        D2 = net(x.to(DEV), torch.tensor(2.5, dtype=torch.float64, device=DEV), y.to(DEV), 1.5)['x']
+        ref2 = O.precond_forward(P, cfg, x, torch.tensor(2.5), y, cfg_scale=1.5, training=False)
+        e2 = _relmax(D2, ref2)
+        print(f'fp32 eval forward vs oracle: {e1:.2e}; with cfg: {e2:.2e}')
+        assert e1 <= TOL_F32 and e2 <= TOL_F32
+        net.set_eval_precision('bf16')
+        Db = net(x.to(DEV), sigma.to(DEV), y.to(DEV))['x']
+        assert 1e-5 < _relmax(Db, ref) <= TOL_D, 'the bf16 plan must still be the bf16 plan'
+    with pytest.raises(ValueError):
+        net.set_eval_precision('fp16')
+    g = _load(golden_dir, 's2_sampler.npz')
+    cfg, P, net = _build('DiT-S/2', 32, int(g['seed']), train=False)
+    labels = torch.eye(1000)[torch.from_numpy(g['cls'])].to(DEV)
+    lat = torch.from_numpy(g['latents']).to(DEV)
+    n = int(g['num_steps'])
+    z = M.edm_sampler(net, lat, labels, cfg_scale=float(g['cfg_scale']), num_steps=n, precision='fp32')
+    e = _relmax(z, torch.from_numpy(g['z']))
+    z_direct = M.edm_sampler(net, lat, labels, cfg_scale=float(g['cfg_scale']), num_steps=n, precision='fp32', use_graph=False)
+    z2 = M.edm_sampler(net, lat, labels, cfg_scale=None, num_steps=n, precision='fp32')
+    e2 = _relmax(z2, torch.from_numpy(g['z_nocfg']))
+    print(f'fp32 sampler vs reference fixture: cfg {e:.2e}, no cfg {e2:.2e}')
+    assert e <= TOL_F32 and e2 <= TOL_F32 and torch.equal(z, z_direct)
+    g = _load(golden_dir, 's2_sampler_churn.npz')
+    cfg, P, net = _build('DiT-S/2', 32, int(g['seed']), train=False)
+    rnd = M.StackedRandomGenerator('cpu', [int(s) for s in g['seeds']])
+    lat = rnd.randn([len(g['seeds']), 4, 32, 32])
+    cls = rnd.randint(1000, size=[len(g['seeds'])])
+    z = M.edm_sampler(net, lat.to(DEV), torch.eye(1000)[cls].to(DEV), cfg_scale=float(g['cfg_scale']), num_steps=int(g['num_steps']),
+                      randn_like=lambda t: rnd.randn(list(t.shape), dtype=t.dtype).to(t.device), S_churn=float(g['S_churn']),
+                      S_min=float(g['S_min']), S_max=float(g['S_max']), S_noise=float(g['S_noise']), precision='fp32')
+    e3 = _relmax(z, torch.from_numpy(g['z']))
+    print(f'fp32 sampler with churn vs reference fixture: {e3:.2e}')
+    assert e3 <= TOL_F32 and net.eval_precision == 'bf16'
+    with pytest.raises(NotImplementedError):
+        net.engine().plan(8, True, True, 128, 'fp32')  # fp32 TRAINING is not provided (train.py --no_amp)
+
+
 def test_generic_net_autograd_path_matches_fused_loss(golden_dir):
     """The reference's own loss arithmetic (train_utils/loss.py:44-52) written in torch on top of
     net(...)['x'] must give the same loss and gradients as the fused EDMLoss."""
