@@ -285,6 +285,12 @@ typedef struct {
 int mdt_gemm_f32(const mdt_gemm_f32_args* a, mdt_stream_t stream);
 /* s[r, :] = softmax(s[r, :n_valid] * scale), in place, columns >= n_valid set to 0 (timm Attention: softmax(q k^T * hd^-0.5)) */
 int mdt_softmax_rows_f32(float* s, long R, int n, int n_valid, float scale, mdt_stream_t stream);
+/* timm Attention (call site models/maskdit.py:178) in exact fp32 on the packed qkv buffer [B*L, 3*H*hd] -> out [B*L, H*hd].
+ * One fused launch (K, V of a (sample, head) resident in LDS, scores in registers) for L in {64, 256}, hd in {32, 64, 72};
+ * other shapes run q k^T -> softmax -> p v through `scores_ws`, which must then hold mdt_attn_f32_ws_floats() floats
+ * (0 = not needed; scores_ws may be NULL). */
+long mdt_attn_f32_ws_floats(int B, int L, int H, int hd);
+int mdt_attn_f32(const float* qkv, float* out, float* scores_ws, int B, int L, int H, int hd, mdt_stream_t stream);
 /* mdt_ln_modulate_fwd with an fp32 result (models/maskdit.py:19-20,177; eps 1e-6) */
 int mdt_ln_modulate_f32(const float* x, const float* shift, const float* scale, int mod_ld, int rows_per_sample,
                         float* xn, int M, int D, mdt_stream_t stream);

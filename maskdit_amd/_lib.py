@@ -93,6 +93,7 @@ _PROTOS = {
     'mdt_lds_poison': [vp],
     'mdt_gemm_f32': [C.POINTER(GemmF32Args)],
     'mdt_softmax_rows_f32': [vp, i64, i32, i32, f32],
+    'mdt_attn_f32': [vp, vp, vp, i32, i32, i32, i32],
     'mdt_ln_modulate_f32': [vp, vp, vp, i32, i32, vp, i32, i32],
     'mdt_timestep_embed_f32': [vp, vp, i32, i32, i32],
     'mdt_silu_f32': [vp, vp, i64],
@@ -111,6 +112,7 @@ _PLAIN = {
     'mdt_set_tuning': [C.c_char_p, i32],
     'mdt_nt8o_report': [C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), i32],
     'mdt_nt8o_stamps': [C.POINTER(C.c_uint64)],
+    'mdt_attn_f32_ws_floats': [i32, i32, i32, i32],
 }
 EXPORTED = sorted(list(_PROTOS) + list(_PLAIN) + ['mdt_last_error', 'mdt_version'])
 ABI_VERSION = 4  # == MDT_ABI_VERSION of include/maskdit_hip.h (tests/test_capi_cpu.py compares the two)
@@ -175,7 +177,7 @@ def lib():
     for name, argt in _PLAIN.items():
         fn = getattr(L, name)
         fn.argtypes = argt
-        fn.restype = i32
+        fn.restype = i64 if name == 'mdt_attn_f32_ws_floats' else i32
     L.mdt_last_error.restype = C.c_char_p
     L.mdt_last_error.argtypes = []
     L.mdt_version.restype = i32

@@ -182,6 +182,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Params p, const int
     const int n = n0 + (wn * NB + jj) * 32 + r;
     if (n >= p.N) continue;
     const float bs = p.bias ? p.bias[n] : 0.f;
+    // the gate of a 4-row group (rows 8 q + 4 kh .. + 3 of a 32-row block): one sample index per group instead of an
+    // integer division per element (rows_per_sample is a multiple of 4 wherever a gate exists; checked by the host entry)
+    float gq[MB][4];
+    if (epi == MDT_F32EPI_GATE_RES) {
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int mq = min(m0 + (wm * MB + i) * 32 + 8 * q + 4 * kh, p.M - 1);
+          gq[i][q] = p.gate ? p.gate[(long)(mq / p.rps) * p.gate_ld + n] : 1.f;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
 #pragma unroll
@@ -192,8 +204,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Params p, const int
         if (epi == MDT_F32EPI_GELU) y = gelu_tanh_f32(y);
         else if (epi == MDT_F32EPI_SILU) y = silu_f32(y);
         else if (epi == MDT_F32EPI_GATE_RES) {
-          const float g = p.gate ? p.gate[(long)(m / p.rps) * p.gate_ld + n] : 1.f;
-          y = p.res[(long)m * p.ldres + n] + g * y;
+          y = p.res[(long)m * p.ldres + n] + gq[i][e >> 2] * y;
         }
         out[(long)m * p.ldo + n] = y;
       }
@@ -225,6 +236,155 @@ __global__ __launch_bounds__(256) void softmax_rows_f32_kernel(float* __restrict
   for (int i = lane; i < n_valid; i += 64) sum += expf(r[i] * scale - mx);
   const float inv = 1.f / wave_sum(sum);
   for (int i = lane; i < n; i += 64) r[i] = i < n_valid ? expf(r[i] * scale - mx) * inv : 0.f;
+}
+
+// the same with the row in registers (n = 256 NV4 floats per row, one 16-byte access per lane and 256 columns): one read,
+// one exp per element, one write -- the three-pass form above runs at 2.6 TB/s on 256-wide rows, this one at the
+// streaming rate
+template <int NV4>
+__global__ __launch_bounds__(256) void softmax_rows_f32_reg_kernel(float* __restrict__ s, long R, float scale) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= R) return;
+  float* r = s + row * (256L * NV4);
+  f32x4 v[NV4];
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) v[i] = *(const f32x4*)(r + 4 * (lane + 64 * i));
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) mx = fmaxf(fmaxf(mx, fmaxf(v[i][0], v[i][1])), fmaxf(v[i][2], v[i][3]));
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV4; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[i][e] = expf((v[i][e] - mx) * scale);
+      sum += v[i][e];
+    }
+  const float inv = 1.f / wave_sum(sum);
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) *(f32x4*)(r + 4 * (lane + 64 * i)) = (f32x4){v[i][0] * inv, v[i][1] * inv, v[i][2] * inv, v[i][3] * inv};
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fused fp32 attention for L <= 256 tokens: one 8-wave workgroup per (sample, head), K and V of the item staged ONCE in
+// LDS as fp32 rows (pitch HD + 4 floats: the 16 rows a ds_read_b128 lane group touches fall on 16 distinct 16-byte bank
+// slots), a wave owns 32 queries.  Scores are computed TRANSPOSED -- S^T = K Q^T with v_mfma_f32_32x32x2_f32, K rows as the
+// A operand from LDS, the wave's Q rows as the B operand from registers -- so a lane holds, for ITS query (column
+// lane & 31), the scores of keys 32 kb + 8 (e / 4) + 4 (lane / 32) + e % 4: the softmax is a per-lane reduction plus one
+// exchange with lane ^ 32, and the probabilities are ALREADY the B operand of O^T = V^T P^T (the two lane halves of
+// accumulator register e are the two contraction slots of one MFMA; the matching V rows come from LDS as 4-byte reads,
+// conflict-free).  Nothing but q, k, v is read and nothing but the output written: the three-launch form (q k^T -> HBM ->
+// softmax -> HBM -> p v) moved 2.1 GB of scores per XL/2 layer at batch 128.
+template <int HD, int L>
+__global__ __launch_bounds__(512) void attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int H, float scale) {
+  constexpr int HDP = HD + 4, KB = L / 32, NJ = HD / 8, NDB = (HD + 31) / 32, CPR = HD / 4;
+  extern __shared__ __attribute__((aligned(16))) float attn_smem[];
+  float* Ks = attn_smem;
+  float* Vs = attn_smem + L * HDP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int W = H * HD;
+  const long ld = 3L * W;
+  const float* base = qkv + (long)b * L * ld + h * HD;
+  constexpr int NCH = L * CPR, IT = (NCH + 511) / 512;
+  {
+    f32x4 kreg[IT], vreg[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int q = min(tid + 512 * i, NCH - 1), row = q / CPR, c = q - row * CPR;
+      kreg[i] = *(const f32x4*)(base + row * ld + W + 4 * c);
+      vreg[i] = *(const f32x4*)(base + row * ld + 2 * W + 4 * c);
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int q = tid + 512 * i, row = q / CPR, c = q - row * CPR;
+      if (q < NCH) {
+        *(f32x4*)(Ks + row * HDP + 4 * c) = kreg[i];
+        *(f32x4*)(Vs + row * HDP + 4 * c) = vreg[i];
+      }
+    }
+  }
+  const int r = lane & 31, kh = lane >> 5, q0 = wave * 32;
+  f32x4 qf[NJ];
+  {
+    const float* qp = base + (long)min(q0 + r, L - 1) * ld + 4 * kh;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) qf[j] = *(const f32x4*)(qp + 8 * j);
+  }
+  __syncthreads();
+  if (q0 >= L) return;
+  f32x16 S[KB];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) S[kb][e] = 0.f;
+    const float* kp = Ks + (32 * kb + r) * HDP + 4 * kh;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const f32x4 kf = *(const f32x4*)(kp + 8 * j);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) S[kb] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[i], qf[j][i], S[kb], 0, 0, 0);
+    }
+  }
+  float mx = -3.0e38f;
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mx = fmaxf(mx, S[kb][e]);
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      S[kb][e] = expf((S[kb][e] - mx) * scale);
+      sum += S[kb][e];
+    }
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.f / sum;
+  f32x16 O[NDB];
+#pragma unroll
+  for (int db = 0; db < NDB; ++db)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) O[db][e] = 0.f;
+  int dcol[NDB];
+#pragma unroll
+  for (int db = 0; db < NDB; ++db) dcol[db] = min(32 * db + r, HD - 1);  // (columns >= HD of the last block are never stored)
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float* vp = Vs + (32 * kb + 8 * (e >> 2) + 4 * kh + (e & 3)) * HDP;
+#pragma unroll
+      for (int db = 0; db < NDB; ++db) O[db] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[dcol[db]], S[kb][e], O[db], 0, 0, 0);
+    }
+  float* op = out + ((long)b * L + q0 + r) * W + h * HD;
+#pragma unroll
+  for (int db = 0; db < NDB; ++db)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int d0 = 32 * db + 8 * q4 + 4 * kh;
+      if (d0 < HD)
+        *(f32x4*)(op + d0) = (f32x4){O[db][4 * q4] * inv, O[db][4 * q4 + 1] * inv, O[db][4 * q4 + 2] * inv, O[db][4 * q4 + 3] * inv};
+    }
+}
+
+template <int HD, int L>
+int launch_attn(const float* qkv, float* out, int B, int H, hipStream_t stream) {
+  constexpr int bytes = 2 * L * (HD + 4) * 4;
+  static bool once = false;
+  if (!once) {
+    if (hipFuncSetAttribute((const void*)attn_f32_kernel<HD, L>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+      mdt_set_error("attn_f32: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+      return MDT_ERR_LAUNCH;
+    }
+    once = true;
+  }
+  const float scale = 1.f / sqrtf((float)HD);
+  hipLaunchKernelGGL((attn_f32_kernel<HD, L>), dim3(B * H), dim3(512), bytes, stream, qkv, out, H, scale);
+  return mdt_check_launch("attn_f32");
 }
 
 // one wave per row; NVT float4 per lane (branch-free, as norm.hip's bf16-output kernel)
@@ -315,6 +475,7 @@ extern "C" int mdt_gemm_f32(const mdt_gemm_f32_args* a, mdt_stream_t stream) {
               "gemm_f32: operand rows must be 16-byte aligned");
   MDT_REQUIRE(a->epi >= MDT_F32EPI_NONE && a->epi <= MDT_F32EPI_GATE_RES, "gemm_f32: unknown epilogue");
   MDT_REQUIRE(a->epi != MDT_F32EPI_GATE_RES || (a->res && a->rows_per_sample > 0), "gemm_f32: GATE_RES needs res and rows_per_sample");
+  MDT_REQUIRE(a->epi != MDT_F32EPI_GATE_RES || !a->gate || a->rows_per_sample % 4 == 0, "gemm_f32: a gate needs rows_per_sample % 4 == 0");
   const int batch = a->batch > 0 ? a->batch : 1;
   const int heads = a->heads > 0 ? a->heads : 1;
   MDT_REQUIRE(batch % heads == 0 && batch <= 65535, "gemm_f32: batch must be a multiple of heads and <= 65535");
@@ -340,7 +501,12 @@ extern "C" int mdt_gemm_f32(const mdt_gemm_f32_args* a, mdt_stream_t stream) {
 extern "C" int mdt_softmax_rows_f32(float* s, long R, int n, int n_valid, float scale, mdt_stream_t stream) {
   MDT_REQUIRE(s && R > 0 && n > 0 && n_valid > 0 && n_valid <= n, "softmax_rows_f32: bad arguments");
   MDT_REQUIRE(cdiv(R, 4) > 0 && R / 4 < 2147483647L, "softmax_rows_f32: too many rows");
-  hipLaunchKernelGGL(f32p::softmax_rows_f32_kernel, dim3(cdiv(R, 4)), dim3(256), 0, (hipStream_t)stream, s, R, n, n_valid, scale);
+  const dim3 grid(cdiv(R, 4)), block(256);
+  const hipStream_t st = (hipStream_t)stream;
+  if (n_valid == n && n == 256) hipLaunchKernelGGL(f32p::softmax_rows_f32_reg_kernel<1>, grid, block, 0, st, s, R, scale);
+  else if (n_valid == n && n == 512) hipLaunchKernelGGL(f32p::softmax_rows_f32_reg_kernel<2>, grid, block, 0, st, s, R, scale);
+  else if (n_valid == n && n == 1024) hipLaunchKernelGGL(f32p::softmax_rows_f32_reg_kernel<4>, grid, block, 0, st, s, R, scale);
+  else hipLaunchKernelGGL(f32p::softmax_rows_f32_kernel, grid, block, 0, st, s, R, n, n_valid, scale);
   return mdt_check_launch("softmax_rows_f32");
 }
 
@@ -378,4 +544,46 @@ extern "C" int mdt_add_rows_f32(const float* in, const float* rows, float* out, 
   const long nq = n_rows * (D / 4);
   hipLaunchKernelGGL(f32p::add_rows_f32_kernel, dim3(cdiv(nq, 256)), dim3(256), 0, (hipStream_t)stream, in, rows, out, nq, T, D / 4);
   return mdt_check_launch("add_rows_f32");
+}
+
+// timm Attention (call site models/maskdit.py:178) in exact fp32 on the packed qkv buffer [B * L, 3 * H * hd]:
+// out [B * L, H * hd] = softmax(q k^T hd^-0.5) v.  Fused single-launch kernel for L in {64, 256} and hd in {32, 64, 72}
+// (every shipped 256^2-latent configuration); otherwise three launches through `scores_ws` (B * H * L * L floats):
+// batched q k^T, in-place row softmax, batched p v.
+static bool attn_f32_fused(int L, int hd) { return (L == 64 || L == 256) && (hd == 32 || hd == 64 || hd == 72); }
+
+extern "C" long mdt_attn_f32_ws_floats(int B, int L, int H, int hd) {
+  return attn_f32_fused(L, hd) ? 0L : (long)B * H * L * L;
+}
+
+extern "C" int mdt_attn_f32(const float* qkv, float* out, float* scores_ws, int B, int L, int H, int hd, mdt_stream_t stream) {
+  MDT_REQUIRE(qkv && out && B > 0 && L > 0 && H > 0 && hd > 0 && hd % 4 == 0, "attn_f32: bad arguments");
+  MDT_REQUIRE(((uintptr_t)qkv & 15) == 0 && ((uintptr_t)out & 15) == 0, "attn_f32: 16-byte aligned buffers");
+  const hipStream_t st = (hipStream_t)stream;
+  if (attn_f32_fused(L, hd) && (long)B * H < 2147483647L) {
+#define ATTN_F32_GO(HDV, LV) return f32p::launch_attn<HDV, LV>(qkv, out, B, H, st);
+    if (L == 256) { if (hd == 72) ATTN_F32_GO(72, 256) else if (hd == 64) ATTN_F32_GO(64, 256) else ATTN_F32_GO(32, 256) }
+    else { if (hd == 72) ATTN_F32_GO(72, 64) else if (hd == 64) ATTN_F32_GO(64, 64) else ATTN_F32_GO(32, 64) }
+#undef ATTN_F32_GO
+  }
+  MDT_REQUIRE(scores_ws, "attn_f32: this shape takes the three-launch form and needs scores_ws (mdt_attn_f32_ws_floats)");
+  MDT_REQUIRE((long)B * H <= 65535, "attn_f32: batch * heads must not exceed 65535 in the three-launch form");
+  const int W = H * hd;
+  mdt_gemm_f32_args g = {};
+  g.A = qkv; g.lda = 3L * W; g.B = qkv + W; g.ldb = 3L * W; g.b_kmajor = 0;
+  g.M = L; g.N = L; g.K = hd; g.epi = MDT_F32EPI_NONE;
+  g.out = scores_ws; g.ldo = L; g.batch = B * H; g.heads = H;
+  g.a_stride_b = (long)L * 3 * W; g.a_stride_h = hd; g.b_stride_b = (long)L * 3 * W; g.b_stride_h = hd;
+  g.o_stride_b = (long)H * L * L; g.o_stride_h = (long)L * L;
+  int rc = mdt_gemm_f32(&g, stream);
+  if (rc != MDT_OK) return rc;
+  rc = mdt_softmax_rows_f32(scores_ws, (long)B * H * L, L, L, 1.f / sqrtf((float)hd), stream);
+  if (rc != MDT_OK) return rc;
+  mdt_gemm_f32_args v = {};
+  v.A = scores_ws; v.lda = L; v.B = qkv + 2 * W; v.ldb = 3L * W; v.b_kmajor = 1;
+  v.M = L; v.N = hd; v.K = L; v.epi = MDT_F32EPI_NONE;
+  v.out = out; v.ldo = W; v.batch = B * H; v.heads = H;
+  v.a_stride_b = (long)H * L * L; v.a_stride_h = (long)L * L; v.b_stride_b = (long)L * 3 * W; v.b_stride_h = hd;
+  v.o_stride_b = (long)L * W; v.o_stride_h = hd;
+  return mdt_gemm_f32(&v, stream);
 }

@@ -368,7 +368,7 @@ extern "C" int mdt_gemm_tn(const mdt_gemm_tn_args* a, mdt_stream_t stream) {
   if (tn_variant != 1 && p.n1_valid == a->N1 && p.n2_valid == a->N2 && a->N1 % 128 == 0 && a->N2 % 128 == 0 &&
       a->M % 32 == 0 && a->M >= 8192 && (long)a->N1 * a->N2 >= 256L * 1024) {
     int cs_done = 0;
-    int rc = launch_gemm_tn8(p.A, p.lda, p.B, p.ldb, p.M, p.N1, p.N2, p.C, p.ldc, (hipStream_t)stream, a->colsum_a, &cs_done);
+    int rc = launch_gemm_tn8(p.A, p.lda, p.B, p.ldb, p.M, p.N1, p.N2, p.C, p.ldc, (hipStream_t)stream, a->colsum_a, &cs_done, a->splits);
     if (rc == MDT_OK && a->colsum_a && !cs_done) rc = mdt_colsum_bf16(a->A, a->lda, a->colsum_a, a->M, a->N1, stream);
     return rc;
   }

@@ -194,4 +194,4 @@ int nt8_max_nf(int epi);
 bool nt8o_eligible(const NTParams& p);                               // gemm_nt8o.hip: the wave-specialised overlap form
 int launch_gemm_nt8o(const NTParams& p, int nl, int dbg, hipStream_t stream);
 int launch_gemm_tn8(const bf16* A, int lda, const bf16* B, int ldb, int M, int N1, int N2, float* C, int ldc,
-                    hipStream_t stream, float* colsum_a = nullptr, int* colsum_done = nullptr);
+                    hipStream_t stream, float* colsum_a = nullptr, int* colsum_done = nullptr, int forced_splits = 0);

@@ -376,7 +376,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TN8Params p) {
 
 // colsum_a (optional): column sums of A.  Folded into the kernel when A takes the X role; returns 1 in *colsum_done then.
 int launch_gemm_tn8(const bf16* A, int lda, const bf16* B, int ldb, int M, int N1, int N2, float* C, int ldc,
-                    hipStream_t stream, float* colsum_a, int* colsum_done) {
+                    hipStream_t stream, float* colsum_a, int* colsum_done, int forced_splits) {
   TN8Params p;
   // Role assignment.  The 192-wide Y tile (YF = 6) wins whenever one width divides by 192: among the legal
   // assignments take the one that wastes the fewest MFMAs on the ragged 256-wide X tile; otherwise the 256 x 128 shape
@@ -419,7 +419,9 @@ int launch_gemm_tn8(const bf16* A, int lda, const bf16* B, int ldb, int M, int N
   // ~ prologue latency + 32K-48K epilogue atomics, worth about 48 slots of MFMA work)
   int best = 1;
   double best_cost = 1e30;
-  for (int sp = 1; sp <= 64; ++sp) {
+  // mdt_gemm_tn_args.splits > 0: the caller's split count (tools/tn8_fixed_cost.py fits the per-block fixed cost with it)
+  if (forced_splits > 0) best = forced_splits < p.slots_total / nslot ? forced_splits : (p.slots_total / nslot > 0 ? p.slots_total / nslot : 1);
+  for (int sp = 1; sp <= 64 && forced_splits <= 0; ++sp) {
     if (sp > 1 && p.slots_total / sp < 32) break;
     const long blocks = (long)tiles * sp;
     const double cost = (double)((blocks + cus - 1) / cus) * ((double)((p.slots_total + sp - 1) / sp) + 48.0);

@@ -769,7 +769,8 @@ class PassPlan:
         sh1, sc1, g1, sh2, sc2, g2 = (mp + 4 * (moff + k * W) for k in range(6))
         xn = self.f32(f'xn_{tag}', M, W)
         qkv = self.f32(f'qkv_{tag}', M, 3 * W)
-        S = self.f32(f'scores_{tag}', B * heads * rows, rows)
+        ws_floats = int(_lib.lib().mdt_attn_f32_ws_floats(B, rows, heads, hd))  # 0: the fused single-launch kernel serves this shape
+        S = self.f32(f'scores_{tag}', ws_floats) if ws_floats else None
         ao = self.f32(f'ao_{tag}', M, W)
         xmid = self.f32(f'xmid_{tag}', M, W)
         h = self.f32(f'h_{tag}', M, 4 * W)
@@ -777,12 +778,7 @@ class PassPlan:
         f.add('mdt_ln_modulate_f32', x_in.data_ptr(), sh1, sc1, NM, rows, xn.data_ptr(), M, W)
         self._g32(xn, W, Pf('attn.qkv.weight'), W, M, 3 * W, W, qkv, 3 * W, bias=Pf('attn.qkv.bias'))
         # timm Attention: softmax(q k^T * hd^-0.5) v per (sample, head) on the packed [M, (3, heads, hd)] buffer
-        q0 = qkv.data_ptr()
-        self._g32(q0, 3 * W, q0 + 4 * W, 3 * W, rows, rows, hd, S, rows, batch=B * heads, heads=heads,
-                  a_s=(rows * 3 * W, hd), b_s=(rows * 3 * W, hd), o_s=(heads * rows * rows, rows * rows))
-        f.add('mdt_softmax_rows_f32', S.data_ptr(), B * heads * rows, rows, rows, float(hd) ** -0.5)
-        self._g32(S, rows, q0 + 8 * W, 3 * W, rows, hd, rows, ao, W, b_kmajor=1, batch=B * heads, heads=heads,
-                  a_s=(heads * rows * rows, rows * rows), b_s=(rows * 3 * W, hd), o_s=(rows * W, hd))
+        f.add('mdt_attn_f32', qkv.data_ptr(), ao.data_ptr(), S.data_ptr() if S is not None else None, B, rows, heads, hd)
         self._g32(ao, W, Pf('attn.proj.weight'), W, M, W, W, xmid, W, bias=Pf('attn.proj.bias'), epi=F32EPI_GATE_RES,
                   res=x_in, ldres=W, gate=g1, gate_ld=NM, rps=rows)
         f.add('mdt_ln_modulate_f32', xmid.data_ptr(), sh2, sc2, NM, rows, xn.data_ptr(), M, W)

@@ -144,11 +144,18 @@ def gemm_f32(A, Bw, out, M, N, K, lda=None, ldb=None, ldo=None, bias=None, epi=F
     return out
 
 
-def attention_f32(qkv, B, L, H, hd):
-    """timm Attention's softmax(q k^T hd^-0.5) v on a packed fp32 [B*L, 3*H*hd] buffer, as the fp32 plans run it."""
+def attention_f32(qkv, B, L, H, hd, three_launch=False):
+    """timm Attention's softmax(q k^T hd^-0.5) v on a packed fp32 [B*L, 3*H*hd] buffer, as the fp32 plans run it
+    (mdt_attn_f32: fused kernel where the shape allows).  three_launch=True: the general q k^T -> softmax -> p v form
+    spelled out with the batched GEMM entry (what mdt_attn_f32 itself falls back to)."""
     W = H * hd
-    S = torch.empty(B * H * L, L, device=qkv.device, dtype=torch.float32)
     o = torch.empty(B * L, W, device=qkv.device, dtype=torch.float32)
+    if not three_launch:
+        n = int(_lib.lib().mdt_attn_f32_ws_floats(B, L, H, hd))
+        ws = torch.empty(n, device=qkv.device, dtype=torch.float32) if n else None
+        call('mdt_attn_f32', p(qkv), p(o), p(ws), B, L, H, hd, stream_ptr())
+        return o
+    S = torch.empty(B * H * L, L, device=qkv.device, dtype=torch.float32)
     gemm_f32(qkv, qkv, S, L, L, hd, lda=3 * W, ldb=3 * W, ldo=L, batch=B * H, heads=H, a_strides=(L * 3 * W, hd),
              b_strides=(L * 3 * W, hd), o_strides=(H * L * L, L * L), b_off=W)
     call('mdt_softmax_rows_f32', p(S), B * H * L, L, L, float(hd) ** -0.5, stream_ptr())

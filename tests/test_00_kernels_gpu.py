@@ -1037,7 +1037,7 @@ def _f32_close(got, ref64, tol, what):
 
 
 @pytest.mark.parametrize('M,N,K,epi', [(300, 200, 256, 'NONE'), (128, 1152, 1152, 'GELU'), (257, 96, 1000, 'SILU'),
-                                        (512, 384, 1536, 'GATE_RES'), (64, 3456, 72, 'NONE'), (130, 40, 36, 'GATE_RES'),
+                                        (512, 384, 1536, 'GATE_RES'), (64, 3456, 72, 'NONE'), (132, 40, 36, 'GATE_RES'),
                                         (2048, 1152, 4608, 'GATE_RES'), (33, 20, 4, 'NONE')])
 def test_gemm_f32_vs_fp64(M, N, K, epi):
     """mdt_gemm_f32: every epilogue, ragged M / N / K tiles (K only needs % 4), the three column-tile widths."""
@@ -1053,7 +1053,7 @@ def test_gemm_f32_vs_fp64(M, N, K, epi):
     elif epi == 'SILU':
         ref = F.silu(ref)
     elif epi == 'GATE_RES':
-        rps = 64 if M % 64 == 0 else 1
+        rps = 64 if M % 64 == 0 else 4
         res = torch.randn(M, N, device=DEV)
         gate = torch.randn(M // rps, N + 8, device=DEV)
         kw.update(res=res, gate=gate, gate_ld=N + 8, rows_per_sample=rps)
@@ -1069,18 +1069,25 @@ def test_gemm_f32_vs_fp64(M, N, K, epi):
         _f32_close(out2, ref, 2e-6, f'gemm_f32 k-major {M}x{N}x{K}')
 
 
-@pytest.mark.parametrize('B_,L,H,hd', [(3, 256, 16, 72), (2, 256, 16, 32), (2, 64, 6, 64), (1, 1024, 2, 32), (2, 128, 3, 80)])
+@pytest.mark.parametrize('B_,L,H,hd', [(3, 256, 16, 72), (2, 256, 16, 32), (2, 64, 6, 64), (2, 256, 6, 64), (3, 64, 16, 72),
+                                       (5, 64, 3, 32), (1, 1024, 2, 32), (2, 128, 3, 80), (1, 512, 2, 72)])
 def test_attention_f32_vs_fp64(B_, L, H, hd):
-    """The fp32 plans' attention (batched q k^T -> in-place row softmax -> batched p v on the packed qkv buffer)."""
+    """mdt_attn_f32: the fused kernel (L 64 / 256, hd 32 / 64 / 72: K, V resident in LDS, scores in registers) and the
+    three-launch form (batched q k^T -> in-place row softmax -> batched p v) for the other shapes, both against fp64."""
     torch.manual_seed(9)
     W = H * hd
     qkv = torch.randn(B_ * L, 3 * W, device=DEV)
-    o = ops.attention_f32(qkv, B_, L, H, hd)
     q, k, v = qkv.double().view(B_, L, 3, H, hd).permute(2, 0, 3, 1, 4)
     ref = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, -1) @ v
     ref = ref.permute(0, 2, 1, 3).reshape(B_ * L, W)
+    fused = int(_lib.lib().mdt_attn_f32_ws_floats(B_, L, H, hd)) == 0
+    assert fused == (L in (64, 256) and hd in (32, 64, 72))
+    _poison_lds()
+    o = ops.attention_f32(qkv, B_, L, H, hd)
     e = _f32_close(o, ref, 2e-6, f'attention_f32 B{B_} L{L} H{H} hd{hd}')
-    print(f'attention_f32 B{B_} L{L} H{H} hd{hd}: rel-to-max err {e:.2e}')
+    o3 = ops.attention_f32(qkv, B_, L, H, hd, three_launch=True)
+    e3 = _f32_close(o3, ref, 2e-6, f'attention_f32 (three launches) B{B_} L{L} H{H} hd{hd}')
+    print(f'attention_f32 B{B_} L{L} H{H} hd{hd}: {"fused" if fused else "3-launch"} rel-to-max err {e:.2e}, spelled-out form {e3:.2e}')
 
 
 @pytest.mark.parametrize('B_,L,D', [(3, 128, 1152), (2, 64, 512), (5, 16, 384), (3, 16, 1280)])
