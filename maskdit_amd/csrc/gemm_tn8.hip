@@ -50,6 +50,13 @@ struct TN8Params {
   float* colsum_x;     // optional [NX]: += column sums of X over this launch's rows (see the kernel)
   int group_x;         // X tiles per group of the tile order (the 32 concurrent workgroups of an XCD cover group_x x 32/group_x tiles)
   int dbg;             // timing experiments only (knob tn8_dbg): 1 = no slot refills, 2 = no fragment reads, 4 = refills re-read the first slots
+  // "long + tail" partition of the contraction (round 6; long_k = 0: uniform splits).  The first tiles * long_k blocks are
+  // LONG: every tile gets long_k of them, each walking long_len slots -- in lock-step over the same rows, like the uniform
+  // splits, so operand rows are shared in L2.  They occupy tiles * long_k of the CUs for the whole launch; the rows that are
+  // left (slots >= long_k * long_len) are one TAIL block per tile, which the dispatcher hands to the remaining CUs as they
+  // come free.  Blocks per CU drop from ~3 (756 uniform blocks on 256 CUs for the XL/2 fc1 / fc2 weight gradients) to 1 on
+  // five CUs of six; each block costs ~32 us on top of its slots (tools/tn8_fixed_cost.py).
+  int long_k, long_len;
 };
 
 // ds_read_b64_tr_b16 through inline asm: with the builtin, hipcc's waitcnt pass assumes the read may
@@ -91,13 +98,29 @@ __global__ __launch_bounds__(512, 2) void gemm_tn8_kernel(TN8Params p) {
   const bool mover2 = YF == 6 && wave < 4;  // this wave also moves the 64-column piece of Y
 
   const int tiles = p.tiles_x * p.tiles_y;
-  const int sid = xcd_remap(blockIdx.x, gridDim.x);
-  const int split = sid / tiles;
+  int tile, s_begin, S;
+  if (p.long_k == 0) {  // uniform splits: block = (split, tile), XCD-contiguous ids
+    const int sid = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = sid / tiles;
+    tile = sid - split * tiles;
+    s_begin = split * p.slots_per_split;
+    S = min(p.slots_per_split, p.slots_total - s_begin);  // >= NSLOT (host guarantees)
+  } else {
+    const int nlong = tiles * p.long_k;
+    if ((int)blockIdx.x < nlong) {  // long block (dispatched first: lowest ids): row group sid / tiles of tile sid % tiles
+      const int sid = xcd_remap(blockIdx.x, nlong);
+      tile = sid % tiles;
+      s_begin = (sid / tiles) * p.long_len;
+      S = p.long_len;
+    } else {  // tail block: the left-over rows of one tile
+      tile = blockIdx.x - nlong;
+      s_begin = p.long_k * p.long_len;
+      S = p.slots_total - s_begin;
+    }
+  }
   int tx, ty;
-  tile_coords(sid - split * tiles, p.tiles_x, p.tiles_y, tx, ty, p.group_x);
+  tile_coords(tile, p.tiles_x, p.tiles_y, tx, ty, p.group_x);
   const int x0 = tx * 256, y0 = ty * Cfg::TY;
-  const int s_begin = split * p.slots_per_split;
-  const int S = min(p.slots_per_split, p.slots_total - s_begin);  // >= NSLOT (host guarantees)
   if (S <= 0) return;
 
   // ---- LDS-DMA addressing: per slot a wave moves rows 4w..4w+3 of X half 0, X half 1 and Y[0,128);
@@ -419,12 +442,15 @@ int launch_gemm_tn8(const bf16* A, int lda, const bf16* B, int ldb, int M, int N
   // ~ prologue latency + 32K-48K epilogue atomics, worth about 48 slots of MFMA work)
   int best = 1;
   double best_cost = 1e30;
+  // per-block fixed cost in slots of MFMA work: ring fill, dispatch, 32K-48K fp32 atomics per wave pair.  Fitted on
+  // MI355X (tools/tn8_fixed_cost.py, profiles/r6_tn8_fixed_cost.txt): 32-38 us = 63-80 slots (rounds 2-5 assumed 48)
+  const double FIXED = 64.0;
   // mdt_gemm_tn_args.splits > 0: the caller's split count (tools/tn8_fixed_cost.py fits the per-block fixed cost with it)
   if (forced_splits > 0) best = forced_splits < p.slots_total / nslot ? forced_splits : (p.slots_total / nslot > 0 ? p.slots_total / nslot : 1);
   for (int sp = 1; sp <= 64 && forced_splits <= 0; ++sp) {
     if (sp > 1 && p.slots_total / sp < 32) break;
     const long blocks = (long)tiles * sp;
-    const double cost = (double)((blocks + cus - 1) / cus) * ((double)((p.slots_total + sp - 1) / sp) + 48.0);
+    const double cost = (double)((blocks + cus - 1) / cus) * ((double)((p.slots_total + sp - 1) / sp) + FIXED);
     if (cost < best_cost * 0.98) { best_cost = cost; best = sp; }
   }
   p.slots_per_split = (p.slots_total + best - 1) / best;
@@ -435,7 +461,33 @@ int launch_gemm_tn8(const bf16* A, int lda, const bf16* B, int ldb, int M, int N
     p.slots_per_split = (p.slots_total + splits - 2) / (splits - 1);
     splits = (p.slots_total + p.slots_per_split - 1) / p.slots_per_split;
   }
-  const dim3 grid(tiles * splits), block(512);
+  int grid_n = tiles * splits;
+  // ---- long + tail partition (TN8Params): k = cus / tiles long blocks per tile of L slots; the R = cus - k tiles other CUs
+  // work through the `tiles` tail blocks in n = ceil(tiles / R) rounds.  L balances the two kinds of CU:
+  // L + FIXED = n (TAIL (S - k L) + FIXED).  TAIL = 1.35: a tail block runs 1.25-1.35x slower per slot than a long one --
+  // only R / 8 workgroups of its XCD read its rows at the same time (27-32 for the long blocks), so its refills are L2
+  // misses (measured, profiles/r6_tn8_long_tail_ab.txt: with TAIL = 1.1 the model took this form for the XL/2 fc1 / fc2
+  // weight gradients at 131072 rows and they ran 6 % SLOWER than 7 uniform splits; proj, where the tails are a 4 % share,
+  // ran 4.6 % faster, and fc1 / fc2 at 16384 rows 2-4 % faster).  Taken when the model predicts >= 3 % less than the best
+  // uniform split: proj at batch 1024, fc1 / fc2 at per-GPU batch 128.  "tn8_dbg" bit 8 = uniform splits only (A/B runs).
+  p.long_k = p.long_len = 0;
+  if (forced_splits <= 0 && !((p.dbg >> 8) & 1) && tiles < cus) {
+    const int k = cus / tiles, R = cus - k * tiles;
+    if (R > 0) {
+      const int n = (tiles + R - 1) / R;
+      const double TAIL = 1.35, S = (double)p.slots_total;
+      int L = (int)((n * TAIL * S + (n - 1) * FIXED) / (1.0 + n * TAIL * k));
+      if ((long)L * k > p.slots_total - 16) L = (p.slots_total - 16) / k;
+      const int tail = p.slots_total - k * L;
+      const double cost = fmax((double)L + FIXED, n * (TAIL * tail + FIXED));
+      if (L >= 32 && tail >= 16 && tail >= nslot && cost < 0.97 * best_cost) {
+        p.long_k = k;
+        p.long_len = L;
+        grid_n = tiles * k + tiles;
+      }
+    }
+  }
+  const dim3 grid(grid_n), block(512);
   const bool fine = (p.dbg & 8) == 0;  // tn8_dbg bit 3: the round-2 staggered form (A/B runs)
   const bool cs = p.colsum_x != nullptr;  // (only with swap == 0: the column sums are those of the X operand = A)
 #define TN8_LAUNCH2(SW, YFV, CSV) { if (fine) hipLaunchKernelGGL((gemm_tn8_kernel<SW, YFV, true, CSV>), grid, block, 0, stream, p); \
