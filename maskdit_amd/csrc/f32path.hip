@@ -25,12 +25,13 @@
 // all 32 k; a 16-byte-chunk XOR swizzle (chunk ^ row & 7) spreads the rows of a fragment over the banks.
 #include "common.h"
 #include "../../include/maskdit_hip.h"
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 namespace f32p {
-
-constexpr int BK = 32;  // floats per K-tile = 128-byte LDS rows
 
 struct Params {
   const float* A; long lda;
@@ -43,6 +44,8 @@ struct Params {
   const float* gate; long gate_ld; int rps;
   int heads;
   long a_sb, a_sh, b_sb, b_sh, o_sb, o_sh;
+  int vec_ok;  // 16-byte epilogue accesses are legal: out / res / gate / bias pitches and bases are multiples of 4 floats
+  int dbg;  // experiments build only (MDT_F32_ABLATE: 1 = no global loads / LDS stores in the K loop, 2 = no barrier, 4 = no fragment reads; garbage results)
 };
 
 // exact-form activations (torch: F.gelu(approximate='tanh'), F.silu) -- the bf16 path's exp2 / rcp forms are 1-ulp
@@ -53,24 +56,34 @@ __device__ __forceinline__ float gelu_tanh_f32(float x) {
 }
 __device__ __forceinline__ float silu_f32(float x) { return x / (1.f + expf(-x)); }
 
-template <int WM, int WN, int MB, int NB, bool BKM>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const Params p, const int tiles_m, const int tiles_n) {
+// BKT = floats per K-tile (32 or 16): 128-byte or 64-byte LDS rows of BKT / 4 16-byte chunks, chunk c of row r stored at
+// chunk c ^ (r & (BKT / 4 - 1)).
+template <int WM, int WN, int MB, int NB, int BKT, bool BKM>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const Params p, const int tiles_m, const int tiles_n) {
   constexpr int BM = WM * MB * 32, BN = WN * NB * 32;
+  constexpr int CPRW = BKT / 4, NG = BKT / 8;        // 16-byte chunks per row; step groups (8 k each) per K-tile
   static_assert(WM * WN == 4, "four waves");
-  constexpr int A_CH = BM * 8 / 256;                 // 16-byte chunks per thread and K-tile
-  constexpr int B_CH = BN * 8 / 256;
+  static_assert(BKT == 16 || BKT == 32, "K-tile depth");
+  constexpr int A_CH = BM * CPRW / 256;              // 16-byte chunks per thread and K-tile
+  constexpr int B_CH = BN * CPRW / 256;
   static_assert(A_CH >= 1 && B_CH >= 1, "tile too small for 256 threads");
-  __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * BK];
+  __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * BKT];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  // XCD-contiguous tile ids (block b runs on XCD b % 8): consecutive tiles -- which share an A row panel -- land in one L2
+  // XCD-contiguous tile ids (block b runs on XCD b % 8)
   const int nt = tiles_m * tiles_n;
   int t = blockIdx.x;
   {
     const int q = nt >> 3, r = nt & 7, x = t & 7, i = t >> 3;
     t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
   }
-  const int tm = t / tiles_n, tn = t - tm * tiles_n;
+  // grouped order: 8 row panels x 1 column panel, next column panel, ... -- the workgroups an XCD holds at a time cover
+  // ~8 x 8 panels whose current K-tiles live in its L2 while they advance together (row-major order: L2 hit rate 0.49,
+  // this order 0.80 -- profiles/r6_f32_pmc.txt; by itself it did not change the launch time, see the K-loop note below).
+  constexpr int GM = 8;
+  const int per_group = GM * tiles_n, grp = t / per_group, first_m = grp * GM;
+  const int gm = min(tiles_m - first_m, GM), in_g = t - grp * per_group;
+  const int tm = first_m + in_g % gm, tn = in_g / gm;
   const int m0 = tm * BM, n0 = tn * BN;
   const int z = blockIdx.y, zb = z / p.heads, zh = z - zb * p.heads;
   const float* __restrict__ A = p.A + zb * p.a_sb + zh * p.a_sh;
@@ -85,140 +98,224 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const Params p, const int
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  f32x4 ga[A_CH], gb[B_CH];
-  auto gload = [&](int k0) {
+  // ---- global -> register staging, TWO K-tiles ahead (two register sets): a load issued at the top of iteration kt is
+  // stored to LDS at the end of iteration kt + 1, so no wave ever parks on vmcnt for a load younger than a whole K-tile
+  // of MFMAs.  Row pointers / row masks are loop-invariant; the K bound only matters in the last K-tile.
+  f32x4 ga[2][A_CH], gb[2][B_CH];
+  const float* pa[A_CH];
+  const float* pb[B_CH];
+  bool oka[A_CH], okb[B_CH];
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-      const int q = tid + 256 * i, row = q >> 3, c = q & 7;
-      const bool ok = (m0 + row) < p.M && (k0 + 4 * c) < p.K;
-      const float* src = A + (long)min(m0 + row, p.M - 1) * p.lda + min(k0 + 4 * c, p.K - 4);
-      const f32x4 v = *(const f32x4*)src;
-      ga[i] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+  for (int i = 0; i < A_CH; ++i) {
+    const int q = tid + 256 * i, row = q / CPRW, c = q % CPRW;
+    oka[i] = (m0 + row) < p.M;
+    pa[i] = A + (long)min(m0 + row, p.M - 1) * p.lda + 4 * c;
+  }
+#pragma unroll
+  for (int i = 0; i < B_CH; ++i) {
+    const int q = tid + 256 * i;
     if (!BKM) {
+      const int row = q / CPRW, c = q % CPRW;
+      okb[i] = (n0 + row) < p.N;
+      pb[i] = Bm + (long)min(n0 + row, p.N - 1) * p.ldb + 4 * c;
+    } else {  // B is [K][N]: a K-tile is BKT rows of BN floats; chunk q = row kr = q / (BN / 4), columns 4 (q % (BN / 4))
+      const int kr = q / (BN / 4), c = q % (BN / 4);
+      okb[i] = (n0 + 4 * c) < p.N;
+      pb[i] = Bm + (long)kr * p.ldb + min(n0 + 4 * c, p.N - 4);
+    }
+  }
+  const bool k_ragged = (p.K % BKT) != 0;
+  const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto gload = [&](auto set_c, int k0) {
+    constexpr int set = decltype(set_c)::value;
+    if (!k_ragged || k0 + BKT <= p.K) {
 #pragma unroll
-      for (int i = 0; i < B_CH; ++i) {
-        const int q = tid + 256 * i, row = q >> 3, c = q & 7;
-        const bool ok = (n0 + row) < p.N && (k0 + 4 * c) < p.K;
-        const float* src = Bm + (long)min(n0 + row, p.N - 1) * p.ldb + min(k0 + 4 * c, p.K - 4);
-        const f32x4 v = *(const f32x4*)src;
-        gb[i] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < A_CH; ++i) {
+        const f32x4 v = *(const f32x4*)(pa[i] + k0);
+        ga[set][i] = oka[i] ? v : zero4;
       }
-    } else {  // B is [K][N]: a K-tile is 32 rows of BN floats
 #pragma unroll
       for (int i = 0; i < B_CH; ++i) {
-        const int q = tid + 256 * i, kr = q / (BN / 4), c = q % (BN / 4);
-        const bool ok = (k0 + kr) < p.K && (n0 + 4 * c) < p.N;
-        const float* src = Bm + (long)min(k0 + kr, p.K - 1) * p.ldb + min(n0 + 4 * c, p.N - 4);
-        const f32x4 v = *(const f32x4*)src;
-        gb[i] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 v = *(const f32x4*)(BKM ? pb[i] + (long)k0 * p.ldb : pb[i] + k0);
+        gb[set][i] = okb[i] ? v : zero4;
+      }
+    } else {  // last, partial K-tile: chunks at or beyond K read as zeros (addresses stay inside the operands)
+#pragma unroll
+      for (int i = 0; i < A_CH; ++i) {
+        const int c4 = 4 * ((tid + 256 * i) % CPRW);
+        const f32x4 v = *(const f32x4*)(pa[i] + min(k0, p.K - 4 - c4));
+        ga[set][i] = (oka[i] && k0 + c4 < p.K) ? v : zero4;
+      }
+#pragma unroll
+      for (int i = 0; i < B_CH; ++i) {
+        if (!BKM) {
+          const int c4 = 4 * ((tid + 256 * i) % CPRW);
+          const f32x4 v = *(const f32x4*)(pb[i] + min(k0, p.K - 4 - c4));
+          gb[set][i] = (okb[i] && k0 + c4 < p.K) ? v : zero4;
+        } else {
+          const int kr = (tid + 256 * i) / (BN / 4);
+          const f32x4 v = *(const f32x4*)(pb[i] + (long)min(k0, p.K - 1 - kr) * p.ldb);
+          gb[set][i] = (okb[i] && k0 + kr < p.K) ? v : zero4;
+        }
       }
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](auto set_c, int buf) {
+    constexpr int set = decltype(set_c)::value;
     float* la = lds[buf];
-    float* lb = lds[buf] + BM * BK;
+    float* lb = lds[buf] + BM * BKT;
 #pragma unroll
     for (int i = 0; i < A_CH; ++i) {
-      const int q = tid + 256 * i, row = q >> 3, c = q & 7;
-      *(f32x4*)(la + row * BK + 4 * (c ^ (row & 7))) = ga[i];
+      const int q = tid + 256 * i, row = q / CPRW, c = q % CPRW;
+      *(f32x4*)(la + row * BKT + 4 * (c ^ (row & (CPRW - 1)))) = ga[set][i];
     }
 #pragma unroll
     for (int i = 0; i < B_CH; ++i) {
       const int q = tid + 256 * i;
       if (!BKM) {
-        const int row = q >> 3, c = q & 7;
-        *(f32x4*)(lb + row * BK + 4 * (c ^ (row & 7))) = gb[i];
+        const int row = q / CPRW, c = q % CPRW;
+        *(f32x4*)(lb + row * BKT + 4 * (c ^ (row & (CPRW - 1)))) = gb[set][i];
       } else {
-        *(f32x4*)(lb + 4 * q) = gb[i];  // [kr][BN], kr = q / (BN / 4)
+        *(f32x4*)(lb + 4 * q) = gb[set][i];  // [kr][BN], kr = q / (BN / 4)
       }
     }
   };
 
-  const int nk = (p.K + BK - 1) / BK;
-  gload(0);
-  lstore(0);
-  __syncthreads();
+  const int nk = (p.K + BKT - 1) / BKT;
   const int r = lane & 31, kh = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) gload((kt + 1) * BK);
-    const float* la = lds[buf] + (wm * MB * 32) * BK;
-    const float* lb = lds[buf] + BM * BK;
+  // fragment sets: [set][block] = the four k of step group j (8 k: k = 8 j + 4 kh + e) of a 32-row block
+  f32x4 fa[2][MB], fb[2][NB];
+  auto fload = [&](int set, int buf, int j) {
+    const float* la = lds[buf] + (wm * MB * 32) * BKT;
+    const float* lb = lds[buf] + BM * BKT;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f32x4 af[MB], bf[NB];
-#pragma unroll
-      for (int i = 0; i < MB; ++i) {
-        const int row = 32 * i + r;  // (tile row & 7) == (row & 7): wm * MB * 32 is a multiple of 8
-        af[i] = *(const f32x4*)(la + row * BK + 4 * ((2 * j + kh) ^ (row & 7)));
-      }
-#pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const int col = (wn * NB + i) * 32 + r;
-        if (!BKM) {
-          bf[i] = *(const f32x4*)(lb + col * BK + 4 * ((2 * j + kh) ^ (col & 7)));
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bf[i][e] = lb[(8 * j + 4 * kh + e) * BN + col];
-        }
-      }
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < MB; ++i)
-#pragma unroll
-          for (int jj = 0; jj < NB; ++jj)
-            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[jj][e], acc[i][jj], 0, 0, 0);
+    for (int i = 0; i < MB; ++i) {
+      const int row = 32 * i + r;  // (tile row & 7) == (row & 7): wm * MB * 32 is a multiple of 8
+      fa[set][i] = *(const f32x4*)(la + row * BKT + 4 * ((2 * j + kh) ^ (row & (CPRW - 1))));
     }
-    if (kt + 1 < nk) lstore(buf ^ 1);
-    __syncthreads();
-  }
-
-  // epilogue: lane holds column n = lane & 31 of rows 8 (e / 4) + 4 (lane / 32) + e % 4 of each 32 x 32 block
-  const int epi = p.epi;
 #pragma unroll
-  for (int jj = 0; jj < NB; ++jj) {
-    const int n = n0 + (wn * NB + jj) * 32 + r;
-    if (n >= p.N) continue;
-    const float bs = p.bias ? p.bias[n] : 0.f;
-    // the gate of a 4-row group (rows 8 q + 4 kh .. + 3 of a 32-row block): one sample index per group instead of an
-    // integer division per element (rows_per_sample is a multiple of 4 wherever a gate exists; checked by the host entry)
-    float gq[MB][4];
-    if (epi == MDT_F32EPI_GATE_RES) {
+    for (int i = 0; i < NB; ++i) {
+      const int col = (wn * NB + i) * 32 + r;
+      if (!BKM) {
+        fb[set][i] = *(const f32x4*)(lb + col * BKT + 4 * ((2 * j + kh) ^ (col & (CPRW - 1))));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fb[set][i][e] = lb[(8 * j + 4 * kh + e) * BN + col];
+      }
+    }
+  };
+  // The MFMA takes the B fragment as its first operand: the accumulator block is the TRANSPOSED output block, i.e. a lane
+  // holds, for ONE output row m (= its A row, lane & 31), columns n = 8 (e / 4) + 4 (lane / 32) + e % 4 of the block --
+  // four consecutive n per register quad, so the epilogue moves 16 bytes per lane and access.
+  auto fmma = [&](int set) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
 #pragma unroll
       for (int i = 0; i < MB; ++i)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int mq = min(m0 + (wm * MB + i) * 32 + 8 * q + 4 * kh, p.M - 1);
-          gq[i][q] = p.gate ? p.gate[(long)(mq / p.rps) * p.gate_ld + n] : 1.f;
-        }
+        for (int jj = 0; jj < NB; ++jj)
+          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[set][jj][e], fa[set][i][e], acc[i][jj], 0, 0, 0);
+  };
+  // K loop, software-pipelined by hand: the fragments of step group j + 1 are read BEFORE the 4 MB NB MFMAs of group j,
+  // and the last group of a K-tile runs after the barrier, under the first reads of the next K-tile.  LDS hazards: tile
+  // kt + 1 is stored into the buffer tile kt - 1 was read from; those reads were issued before barrier(kt - 1), which
+  // waits for them (lgkmcnt(0)).
+  // What bounds this kernel (round 6, profiles/r6_f32_*.txt): with every memory instruction of the loop ablated the
+  // launch runs at 133-134 TF/s (0.85 of the 157 TF/s peak: prologue / epilogue per 36-K-tile tile); the global loads +
+  // LDS stores cost 15 % of the full kernel and the fragment reads 9 %.  NOT the barrier (ablating it: no change), not the
+  // LDS read latency (pipelining the reads a whole step group ahead: no change), not L2 misses (hit rate 0.49 -> 0.80 with
+  // the grouped tile order: no change), not the operand bytes (256 x 128 x 16 tile, 23 instead of 31 B / kFLOP: no change).
+  auto step = [&](auto par_c, int kt) {
+    constexpr int par = decltype(par_c)::value;  // = kt & 1: LDS buffer of this K-tile and register set of K-tile kt + 2
+    const bool more = kt + 1 < nk;
+    if (kt + 2 < nk && !MDT_EXP(p.dbg & 1)) gload(par_c, (kt + 2) * BKT);
+#pragma unroll
+    for (int g = 0; g + 1 < NG; ++g) {
+      if (!MDT_EXP(p.dbg & 4)) fload((g + 1) & 1, par, g + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      fmma(g & 1);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    if (more && !MDT_EXP(p.dbg & 1)) lstore(std::integral_constant<int, par ^ 1>{}, par ^ 1);
+    if (!MDT_EXP(p.dbg & 2)) __syncthreads();
+    if (more && !MDT_EXP(p.dbg & 4)) fload(NG & 1, par ^ 1, 0);   // (NG is even: the next tile's group 0 lands in set 0 again)
+    __builtin_amdgcn_sched_barrier(0);
+    fmma((NG - 1) & 1);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  gload(std::integral_constant<int, 0>{}, 0);
+  lstore(std::integral_constant<int, 0>{}, 0);
+  if (nk > 1) gload(std::integral_constant<int, 1>{}, BKT);
+  __syncthreads();
+  fload(0, 0, 0);
+  for (int kt = 0; kt < nk; kt += 2) {
+    step(std::integral_constant<int, 0>{}, kt);
+    if (kt + 1 < nk) step(std::integral_constant<int, 1>{}, kt + 1);
+  }
+
+  // ---- epilogue: the lane's output row m = block row lane & 31; register quad q4 of block jj = columns nq .. nq + 3
+  const int epi = p.epi;
+  const bool vec = p.vec_ok;  // 16-byte accesses legal (pitches / bases multiples of 4 floats; checked by the host entry)
 #pragma unroll
-    for (int i = 0; i < MB; ++i) {
+  for (int i = 0; i < MB; ++i) {
+    const int m = m0 + (wm * MB + i) * 32 + r;
+    if (m >= p.M) continue;
+    float* orow = out + (long)m * p.ldo;
+    const float* rrow = epi == MDT_F32EPI_GATE_RES ? p.res + (long)m * p.ldres : nullptr;
+    const float* grow = (epi == MDT_F32EPI_GATE_RES && p.gate) ? p.gate + (long)(m / p.rps) * p.gate_ld : nullptr;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + (wm * MB + i) * 32 + 8 * (e >> 2) + 4 * kh + (e & 3);
-        if (m >= p.M) continue;
-        float y = acc[i][jj][e] + bs;
-        if (epi == MDT_F32EPI_GELU) y = gelu_tanh_f32(y);
-        else if (epi == MDT_F32EPI_SILU) y = silu_f32(y);
-        else if (epi == MDT_F32EPI_GATE_RES) {
-          y = p.res[(long)m * p.ldres + n] + gq[i][e >> 2] * y;
+    for (int jj = 0; jj < NB; ++jj) {
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int nq = n0 + (wn * NB + jj) * 32 + 8 * q4 + 4 * kh;
+        if (nq >= p.N) continue;
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = acc[i][jj][4 * q4 + e];
+        if (vec && nq + 4 <= p.N) {
+          if (p.bias) {
+            const f32x4 b4 = *(const f32x4*)(p.bias + nq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] += b4[e];
+          }
+          if (epi == MDT_F32EPI_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = gelu_tanh_f32(y[e]);
+          } else if (epi == MDT_F32EPI_SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = silu_f32(y[e]);
+          } else if (epi == MDT_F32EPI_GATE_RES) {
+            const f32x4 r4 = *(const f32x4*)(rrow + nq);
+            f32x4 g4 = (f32x4){1.f, 1.f, 1.f, 1.f};
+            if (grow) g4 = *(const f32x4*)(grow + nq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = r4[e] + g4[e] * y[e];
+          }
+          *(f32x4*)(orow + nq) = (f32x4){y[0], y[1], y[2], y[3]};
+        } else {  // ragged / unaligned: element by element
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int n = nq + e;
+            if (n >= p.N) continue;
+            float v = y[e] + (p.bias ? p.bias[n] : 0.f);
+            if (epi == MDT_F32EPI_GELU) v = gelu_tanh_f32(v);
+            else if (epi == MDT_F32EPI_SILU) v = silu_f32(v);
+            else if (epi == MDT_F32EPI_GATE_RES) v = rrow[n] + (grow ? grow[n] : 1.f) * v;
+            orow[n] = v;
+          }
         }
-        out[(long)m * p.ldo + n] = y;
       }
     }
   }
 }
 
-template <int WM, int WN, int MB, int NB>
+template <int WM, int WN, int MB, int NB, int BKT>
 int launch(const Params& p, bool bkm, int batch, hipStream_t stream) {
   constexpr int BM = WM * MB * 32, BN = WN * NB * 32;
   const int tm = cdiv(p.M, BM), tn = cdiv(p.N, BN);
   const dim3 grid(tm * tn, batch);
-  if (bkm) hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, MB, NB, true>), grid, dim3(256), 0, stream, p, tm, tn);
-  else hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, MB, NB, false>), grid, dim3(256), 0, stream, p, tm, tn);
+  if (bkm) hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, MB, NB, BKT, true>), grid, dim3(256), 0, stream, p, tm, tn);
+  else hipLaunchKernelGGL((gemm_f32_kernel<WM, WN, MB, NB, BKT, false>), grid, dim3(256), 0, stream, p, tm, tn);
   return mdt_check_launch("gemm_f32");
 }
 
@@ -475,7 +572,6 @@ extern "C" int mdt_gemm_f32(const mdt_gemm_f32_args* a, mdt_stream_t stream) {
               "gemm_f32: operand rows must be 16-byte aligned");
   MDT_REQUIRE(a->epi >= MDT_F32EPI_NONE && a->epi <= MDT_F32EPI_GATE_RES, "gemm_f32: unknown epilogue");
   MDT_REQUIRE(a->epi != MDT_F32EPI_GATE_RES || (a->res && a->rows_per_sample > 0), "gemm_f32: GATE_RES needs res and rows_per_sample");
-  MDT_REQUIRE(a->epi != MDT_F32EPI_GATE_RES || !a->gate || a->rows_per_sample % 4 == 0, "gemm_f32: a gate needs rows_per_sample % 4 == 0");
   const int batch = a->batch > 0 ? a->batch : 1;
   const int heads = a->heads > 0 ? a->heads : 1;
   MDT_REQUIRE(batch % heads == 0 && batch <= 65535, "gemm_f32: batch must be a multiple of heads and <= 65535");
@@ -491,11 +587,29 @@ extern "C" int mdt_gemm_f32(const mdt_gemm_f32_args* a, mdt_stream_t stream) {
   p.heads = heads;
   p.a_sb = a->a_stride_b; p.a_sh = a->a_stride_h; p.b_sb = a->b_stride_b; p.b_sh = a->b_stride_h;
   p.o_sb = a->o_stride_b; p.o_sh = a->o_stride_h;
+  p.vec_ok = a->ldo % 4 == 0 && ((uintptr_t)a->out & 15) == 0 && (a->o_stride_b | a->o_stride_h) % 4 == 0 &&
+             (!a->bias || ((uintptr_t)a->bias & 15) == 0) &&
+             (!a->res || (a->ldres % 4 == 0 && ((uintptr_t)a->res & 15) == 0)) &&
+             (!a->gate || (a->gate_ld % 4 == 0 && ((uintptr_t)a->gate & 15) == 0));
+  p.dbg = 0;
+#ifdef MDT_EXPERIMENTS
+  {
+    static int ablate = -1;
+    if (ablate < 0) {
+      const char* e = getenv("MDT_F32_ABLATE");
+      ablate = e ? atoi(e) : 0;
+    }
+    p.dbg = ablate;
+  }
+#endif
   const hipStream_t st = (hipStream_t)stream;
-  // column tile: 128 unless the problem is narrower (attention's p v with N = head_dim)
-  if (a->N > 64) return f32p::launch<2, 2, 2, 2>(p, a->b_kmajor != 0, batch, st);
-  if (a->N > 32) return f32p::launch<4, 1, 1, 2>(p, a->b_kmajor != 0, batch, st);
-  return f32p::launch<4, 1, 1, 1>(p, a->b_kmajor != 0, batch, st);
+  const bool bkm = a->b_kmajor != 0;
+  // column tile: 128 unless the problem is narrower (attention's p v with N = head_dim).  (A 256 x 128 tile with 16-deep
+  // K-tiles -- 23 instead of 31 operand bytes per kFLOP -- measured the same 0.65-0.71 of peak as this one,
+  // profiles/r6_f32_bench_tiles.txt, and does not fit 256 registers with the two-ahead load staging: not instantiated.)
+  if (a->N > 64) return f32p::launch<2, 2, 2, 2, 32>(p, bkm, batch, st);
+  if (a->N > 32) return f32p::launch<4, 1, 1, 2, 32>(p, bkm, batch, st);
+  return f32p::launch<4, 1, 1, 1, 32>(p, bkm, batch, st);
 }
 
 extern "C" int mdt_softmax_rows_f32(float* s, long R, int n, int n_valid, float scale, mdt_stream_t stream) {

@@ -287,6 +287,25 @@ def test_eval_forward_cfg_and_sampler_fp32_vs_oracle(golden_dir):
         net.engine().plan(8, True, True, 128, 'fp32')  # fp32 TRAINING is not provided (train.py --no_amp)
 
 
+def test_eval_forward_fp32_at_1024_tokens_vs_oracle():
+    """The fp32 plan at 512^2-latent token counts (T = 1024: BASELINE configs[3] shapes): attention takes the three-launch
+    form (q k^T -> row softmax -> p v through a scores workspace) instead of the LDS-resident fused kernel."""
+    cfg, P, net = _build('DiT-S/2', 64, seed=11, train=False)
+    net.set_eval_precision('fp32')
+    gcpu = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 4, 64, 64, generator=gcpu) * 2
+    sigma = torch.tensor([0.5, 7.0])
+    y = torch.zeros(2, 1000)
+    y[torch.arange(2), torch.tensor([3, 777])] = 1
+    with torch.no_grad():
+        D = net(x.to(DEV), sigma.to(DEV), y.to(DEV))['x']
+        ref = O.precond_forward(P, cfg, x, sigma, y, training=False)
+    e = _relmax(D, ref)
+    print(f'fp32 eval forward, T = 1024: {e:.2e}')
+    assert e <= TOL_F32
+    assert any(k.startswith('scores_') for k in net.engine().plan(2, False, False, None, 'fp32').buf), 'expected the scores workspace'
+
+
 def test_generic_net_autograd_path_matches_fused_loss(golden_dir):
     """The reference's own loss arithmetic (train_utils/loss.py:44-52) written in torch on top of
     net(...)['x'] must give the same loss and gradients as the fused EDMLoss."""
