@@ -4,7 +4,7 @@ the MI355X engine: per-seed StackedRandomGenerator latents / labels (utils.py:11
 hipGraph-captured EDM Heun sampler with classifier-free guidance, latents written as .npy.
 
     python generate.py --config configs/xl2-256-synthetic.yaml --seeds 0-63 --num_steps 50 --cfg_scale 1.5 \
-        [--ckpt_path 2000000.pt] [--outdir samples]
+        [--ckpt_path 2000000.pt] [--outdir samples] [--precision fp32]
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 generate.py ...   # seeds sharded by rank
 
 Seeds are split over the ranks exactly as sample.py:233-235 does (no exchange step: replicas only).
@@ -55,6 +55,9 @@ def main(argv=None):
     ap.add_argument('--class_idx', type=int, default=None)
     ap.add_argument('--subdirs', action='store_true', help='one sub-directory per 1000 seeds (sample.py:288)')
     ap.add_argument('--pretrained_path', default=None, help='autoencoder_kl.pth: decode the latents to images (sample.py:248)')
+    ap.add_argument('--precision', choices=['bf16', 'fp32'], default='bf16',
+                    help="arithmetic of the network evaluations: 'fp32' = exact fp32 weights / activations / matrix instructions, what "
+                         "the reference's own sampler runs (sample.py:56; ~1/9 of the bf16 throughput); 'bf16' = the training kernels")
     args = ap.parse_args(argv)
     cfg = load_config(args.config)
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -83,7 +86,8 @@ def main(argv=None):
         if args.class_idx is not None:
             labels[:, :] = 0
             labels[:, args.class_idx] = 1
-        z = M.edm_sampler(net, latents, labels, cfg_scale=args.cfg_scale, randn_like=rnd.randn_like, num_steps=args.num_steps)
+        z = M.edm_sampler(net, latents, labels, cfg_scale=args.cfg_scale, randn_like=rnd.randn_like, num_steps=args.num_steps,
+                          precision=args.precision)
         images = None
         if vae is not None:  # sample.py:282-286: decode, [-1, 1] -> uint8 HWC
             images = vae.decode(z.float()).add_(1).mul_(127.5).clamp_(0, 255).to(torch.uint8).permute(0, 2, 3, 1).cpu().numpy()

@@ -220,7 +220,16 @@ def parse(argv=None):
     ap.add_argument('--num_steps', type=int, default=40)
     ap.add_argument('--cfg_scale', type=float, default=None)
     ap.add_argument('--ref_path', default=None)
-    return ap.parse_args(argv)
+    # train.py:305 of the reference: --no_amp = fp32 / TF32 training.  This engine's TRAINING kernels compute in bf16 with an fp32
+    # residual stream / fp32 master weights (the reference under autocast); an fp32 backward does not exist.  The flag is
+    # accepted so that a reference command line fails with a statement of what IS provided, not with an argparse usage error.
+    ap.add_argument('--no_amp', action='store_true', help='not provided: fp32 exists for inference only (generate.py --precision fp32)')
+    args = ap.parse_args(argv)
+    if args.no_amp:
+        ap.error('--no_amp (fp32 training) is not provided by maskdit_amd: training runs bf16 MFMA operands with fp32 accumulation, '
+                 "an fp32 residual stream and fp32 master weights; the fp32-faithful path covers inference (generate.py --precision fp32, "
+                 "edm_sampler(precision='fp32'))")
+    return args
 
 
 def make_batches(cfg, args, dev, rank, world, B):
