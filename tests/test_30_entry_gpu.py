@@ -144,13 +144,14 @@ def test_generate_writes_per_seed_latents(tmp_path):
     b = np.load(os.path.join(tmp, 't', '000007.npy'))
     assert np.abs(a - b).max() <= 2e-2 * np.abs(a).max()  # bf16 network: batch-size-dependent GEMM tiling only
     # --precision fp32 (the reference sampler's own arithmetic, sample.py:56): the same seed in two batch compositions agrees
-    # to fp32 rounding, and the bf16 run above sits within its documented drift of it
+    # to fp32 rounding, and the bf16 run above sits within its documented drift of it (the precision tests proper, on
+    # de-zeroed weights against the reference fixtures: tests/test_10_engine_gpu.py)
     G.main(['--config', cfg, '--seeds', '5-9', '--num_steps', '4', '--cfg_scale', '1.5', '--outdir', os.path.join(tmp, 'f'),
             '--max_batch_size', '3', '--precision', 'fp32'])
     G.main(['--config', cfg, '--seeds', '7', '--num_steps', '4', '--cfg_scale', '1.5', '--outdir', os.path.join(tmp, 'g'), '--precision', 'fp32'])
     fa, fb = np.load(os.path.join(tmp, 'f', '000007.npy')), np.load(os.path.join(tmp, 'g', '000007.npy'))
     assert np.abs(fa - fb).max() <= 1e-5 * np.abs(fa).max()
-    assert 0 < np.abs(a - fa).max() <= 2e-2 * np.abs(fa).max()
+    assert np.abs(a - fa).max() <= 2e-2 * np.abs(fa).max()  # (a freshly initialised model's final layer is zero: F = 0 in both)
 
 
 def test_generate_with_vae_decode_writes_images(tmp_path):

@@ -42,6 +42,20 @@ def test_argument_validation_without_gpu(built):
     assert rc != 0 and b'power of two' in built.mdt_last_error()
     rc = built.mdt_attn_fwd(1, 1, 1, 2, 100, 2, 72, 0, None)
     assert rc != 0 and b'multiple of 64' in built.mdt_last_error()
+    # the fp32-faithful entries (round 6)
+    g = _lib.GemmF32Args()
+    assert built.mdt_gemm_f32(C.byref(g), None) != 0 and b'null pointer' in built.mdt_last_error()
+    g.A, g.B, g.out, g.lda, g.ldb, g.ldo, g.M, g.N, g.K = 16, 16, 16, 8, 8, 8, 4, 4, 6
+    assert built.mdt_gemm_f32(C.byref(g), None) != 0 and b'multiple of 4' in built.mdt_last_error()
+    g.K, g.epi = 8, 3   # GATE_RES without a residual
+    assert built.mdt_gemm_f32(C.byref(g), None) != 0 and b'GATE_RES' in built.mdt_last_error()
+    g.epi, g.batch, g.heads = 0, 6, 4
+    assert built.mdt_gemm_f32(C.byref(g), None) != 0 and b'multiple of heads' in built.mdt_last_error()
+    assert built.mdt_attn_f32_ws_floats(2, 256, 16, 72) == 0            # the fused kernel's domain: no workspace
+    assert built.mdt_attn_f32_ws_floats(2, 1024, 16, 72) == 2 * 16 * 1024 * 1024
+    assert built.mdt_attn_f32(16, 16, None, 2, 1024, 16, 72, None) != 0 and b'scores_ws' in built.mdt_last_error()
+    assert built.mdt_softmax_rows_f32(None, 4, 256, 256, 1.0, None) != 0
+    assert built.mdt_ln_modulate_f32(16, 16, 16, 8, 4, 16, 8, 1300, None) != 0 and b'bad shape' in built.mdt_last_error()
 
 
 def test_experiment_switches_are_not_in_the_product_library(built):
