@@ -125,6 +125,13 @@ int mdt_attn_bwd(const mdt_bf16* qkv, const mdt_bf16* out, const mdt_bf16* dout,
 int mdt_ln_modulate_fwd(const float* x, const float* shift, const float* scale, int mod_ld,
                         int rows_per_sample, mdt_bf16* xn, float* stats, int M, int D,
                         mdt_stream_t stream);
+/* The residual add that feeds the LayerNorm, folded in (round 6): x = xres + gate[b] * y  (`x + gate * f(x)`,
+ * models/maskdit.py:190-191, y = the bf16 branch output a plain mdt_gemm_nt stored), x is written (fp32: the next residual
+ * / the backward's saved input), then xn, stats as mdt_ln_modulate_fwd of x.  Bit-identical to MDT_EPI_GATE_RES followed by
+ * mdt_ln_modulate_fwd, 14 instead of 16 bytes per element. */
+int mdt_ln_modulate_fwd_res(const float* xres, const mdt_bf16* y, const float* gate, int gate_ld, const float* shift,
+                            const float* scale, int mod_ld, int rows_per_sample, float* x, mdt_bf16* xn, float* stats,
+                            int M, int D, mdt_stream_t stream);
 /* backward: dx (+)= dLN(dxn * (1+scale)); dshift[b] += sum_l dxn; dscale[b] += sum_l dxn*xhat. */
 int mdt_ln_modulate_bwd(const mdt_bf16* dxn, const float* x, const float* stats, const float* scale,
                         int mod_ld, int rows_per_sample, float* dx, int accumulate, float* dshift,

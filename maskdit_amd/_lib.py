@@ -53,6 +53,7 @@ _PROTOS = {
     'mdt_attn_fwd': [vp, vp, vp, i32, i32, i32, i32, i32],
     'mdt_attn_bwd': [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32],
     'mdt_ln_modulate_fwd': [vp, vp, vp, i32, i32, vp, vp, i32, i32],
+    'mdt_ln_modulate_fwd_res': [vp, vp, vp, i32, vp, vp, i32, i32, vp, vp, vp, i32, i32],
     'mdt_ln_modulate_bwd': [vp, vp, vp, vp, i32, i32, vp, i32, vp, vp, i32, i32, i32],
     'mdt_ln_modulate_bwd_gate': [vp, vp, vp, vp, i32, i32, vp, i32, vp, vp, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp],
     'mdt_gate_bwd': [vp, vp, vp, i32, i32, vp, vp, i32, vp, i32, i32],

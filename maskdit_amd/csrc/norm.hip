@@ -72,6 +72,81 @@ __global__ __launch_bounds__(256) void ln_modulate_fwd_kernel(const float* __res
 }
 
 // ------------------------------------------------------------------------------------------
+// The residual add that FEEDS a LayerNorm, folded into it (round 6): x = xres + gate[b] * y is what `x + gate * f(x)`
+// (models/maskdit.py:190-191) hands to the next `modulate(norm(x))` (:188-189).  Rounds 1-5 formed x in the epilogue of
+// the GEMM that produced y (MDT_EPI_GATE_RES: fp32 residual in, fp32 x out, bf16 y out = 10 B / element) and then read x
+// again here (6 B / element).  Now that GEMM stores only y (2 B; plain class: its stores hide far better than the
+// residual round trip did) and this pass reads xres (4) + y (2) and writes x (4) + xn (2): 14 instead of 16 B per element
+// and step, and the slowest GEMM class of the training forward (0.17-0.27 of the MFMA peak) becomes the plain one.
+// y is the bf16 value the GEMM stored -- the same rounded value MDT_EPI_GATE_RES added -- so x is bit-identical.
+template <int NVT>
+__global__ __launch_bounds__(256) void ln_modulate_fwd_res_kernel(const float* __restrict__ xres, const bf16* __restrict__ y,
+                                                                  const float* __restrict__ gate, int gate_ld,
+                                                                  const float* __restrict__ shift, const float* __restrict__ scale,
+                                                                  int mod_ld, int rows_per_sample, float* __restrict__ x,
+                                                                  bf16* __restrict__ xn, float* __restrict__ stats, int M, int D) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nv = D >> 2;
+  const float* xr = xres + (long)row * D;
+  const bf16* yr = y + (long)row * D;
+  const long b = row / rows_per_sample;
+  const float* sh = shift + b * mod_ld;
+  const float* sc = scale + b * mod_ld;
+  const float* gt = gate + b * gate_ld;
+  f32x4 v[NVT], a[NVT], m[NVT], g[NVT];
+  bf16x4 yv[NVT];
+  int col[NVT];
+  float own[NVT];
+#pragma unroll
+  for (int i = 0; i < NVT; ++i) {
+    const int c = lane + 64 * i;
+    own[i] = c < nv ? 1.f : 0.f;
+    col[i] = 4 * min(c, nv - 1);
+    v[i] = *(const f32x4*)(xr + col[i]);
+    yv[i] = *(const bf16x4*)(yr + col[i]);
+    g[i] = *(const f32x4*)(gt + col[i]);
+    a[i] = *(const f32x4*)(sh + col[i]);
+    m[i] = *(const f32x4*)(sc + col[i]);
+  }
+  float s = 0.f;
+  float* xo = x + (long)row * D;
+#pragma unroll
+  for (int i = 0; i < NVT; ++i) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[i][e] = v[i][e] + g[i][e] * bf2f(yv[i][e]);  // the GATE_RES epilogue's expression, term for term
+    *(f32x4*)(xo + col[i]) = v[i];
+    s += own[i] * (v[i][0] + v[i][1] + v[i][2] + v[i][3]);
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NVT; ++i) {
+    float qi = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = v[i][e] - mean;
+      qi += d * d;
+    }
+    q += own[i] * qi;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)D + 1e-6f);
+  bf16* o = xn + (long)row * D;
+#pragma unroll
+  for (int i = 0; i < NVT; ++i) {
+    bf16x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r[e] = f2bf((v[i][e] - mean) * rstd * (1.f + m[i][e]) + a[i][e]);
+    *(bf16x4*)(o + col[i]) = r;
+  }
+  if (lane == 0) {
+    stats[2 * (long)row] = mean;
+    stats[2 * (long)row + 1] = rstd;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // grid (B, splits): workgroup handles rows [s*chunk, (s+1)*chunk) of sample b, 4 waves.
 template <bool FUSE_GATE>
 __global__ __launch_bounds__(256) void ln_modulate_bwd_kernel(const bf16* __restrict__ dxn, const float* __restrict__ x,
@@ -480,6 +555,27 @@ extern "C" int mdt_ln_modulate_fwd(const float* x, const float* shift, const flo
   }
 #undef LN_FWD_LAUNCH
   return mdt_check_launch("ln_modulate_fwd");
+}
+
+extern "C" int mdt_ln_modulate_fwd_res(const float* xres, const mdt_bf16* y, const float* gate, int gate_ld, const float* shift,
+                                       const float* scale, int mod_ld, int rows_per_sample, float* x, mdt_bf16* xn, float* stats,
+                                       int M, int D, mdt_stream_t stream) {
+  MDT_REQUIRE(xres && y && gate && shift && scale && x && xn && stats, "ln_modulate_fwd_res: null pointer");
+  MDT_REQUIRE(D % 4 == 0 && D <= MAXV * 256, "ln_modulate_fwd_res: D must be a multiple of 4 and <= 1280");
+  MDT_REQUIRE(M > 0 && rows_per_sample > 0 && M % rows_per_sample == 0, "ln_modulate_fwd_res: M must be B*rows_per_sample");
+  MDT_REQUIRE(gate_ld % 4 == 0 && mod_ld % 4 == 0, "ln_modulate_fwd_res: gate / modulation pitches must be multiples of 4");
+#define LN_FWDR_LAUNCH(N)                                                                                                  \
+  hipLaunchKernelGGL(ln_modulate_fwd_res_kernel<N>, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream, xres, (const bf16*)y, \
+                     gate, gate_ld, shift, scale, mod_ld, rows_per_sample, x, (bf16*)xn, stats, M, D)
+  switch (cdiv(D >> 2, 64)) {
+    case 1: LN_FWDR_LAUNCH(1); break;
+    case 2: LN_FWDR_LAUNCH(2); break;
+    case 3: LN_FWDR_LAUNCH(3); break;
+    case 4: LN_FWDR_LAUNCH(4); break;
+    default: LN_FWDR_LAUNCH(5); break;
+  }
+#undef LN_FWDR_LAUNCH
+  return mdt_check_launch("ln_modulate_fwd_res");
 }
 
 extern "C" int mdt_ln_modulate_bwd(const mdt_bf16* dxn, const float* x, const float* stats, const float* scale,

@@ -53,6 +53,11 @@ FUSE_LN_GATE = os.environ.get('MDT_FUSE_LN_GATE', '1') != '0'
 ADA_GROUP = 7  # encoder blocks per adaLN weight-gradient group (XL/2: 4 groups of 7 + the decoder-side group)
 FUSE_QKV_COLSUM = os.environ.get('MDT_FUSE_QKV_COLSUM', '1') != '0'  # qkv bias gradient out of the qkv weight-gradient GEMM (A/B switch)
 FUSE_COLSUM = os.environ.get('MDT_FUSE_COLSUM', '1') != '0'  # fc1 bias gradient out of the DGELU epilogue (A/B switch)
+# Round 6: in TRAINING plans the residual add `x + gate * f(x)` (models/maskdit.py:190-191) is formed by the LayerNorm pass that
+# consumes it (mdt_ln_modulate_fwd_res) instead of by the epilogue of the GEMM that produced f(x): the proj / fc2 GEMMs store only
+# their bf16 output (plain class) -- 14 instead of 16 B per element, bit-identical x.  MDT_FUSE_RES_LN=0: the MDT_EPI_GATE_RES
+# epilogues of rounds 1-5 (A/B runs).  Inference plans keep GATE_RES: they do not store the branch output at all.
+FUSE_RES_LN = os.environ.get('MDT_FUSE_RES_LN', '1') != '0'
 
 
 def _rup(x, m):
@@ -559,17 +564,25 @@ class PassPlan:
               Pf('model.x_embedder.proj.bias'), eng.pos.data_ptr(), ids32.data_ptr() if ids32 is not None else None,
               2 * T, x0.data_ptr(), B, sp.C, sp.R, sp.patch, L, D)
         xs_e = [x0]
+        fuse = train and FUSE_RES_LN
+        pend = None  # (xres, y, gate address): the residual add the NEXT LayerNorm pass has to perform into xs_e[-1]
         for i in range(sp.depth):
-            xs_e.append(self._block_fwd(f'model.blocks.{i}', 'e', i, xs_e[-1], mod, sp.mod_off('enc', i), D, sp.heads, L, Me,
-                                        lvalid=self.lv_attn))
+            xo, pend = self._block_fwd(f'model.blocks.{i}', 'e', i, xs_e[-1], mod, sp.mod_off('enc', i), D, sp.heads, L, Me,
+                                       lvalid=self.lv_attn, pending=pend, defer_out=fuse)
+            xs_e.append(xo)
         # ---------------- decoder layer + unmask ----------------------------------------------
         self.marks = {'enc_fwd_end': len(f.calls)}  # launch index where the encoder (+ conditioning path) forward ends
         odl = sp.mod_off('dl')
         xnd = self.b16('xn_dl', Me, D)
         st_dl = self.f32('st_dl', Me, 2)
         xdec = self.b16('xdec', Me, Dd)
-        f.add('mdt_ln_modulate_fwd', xs_e[-1].data_ptr(), mod.data_ptr() + 4 * odl, mod.data_ptr() + 4 * (odl + D), NM, L,
-              xnd.data_ptr(), st_dl.data_ptr(), Me, D)
+        if pend is not None:  # the top encoder block's MLP residual is formed here
+            f.add('mdt_ln_modulate_fwd_res', pend[0].data_ptr(), pend[1].data_ptr(), pend[2], NM, mod.data_ptr() + 4 * odl,
+                  mod.data_ptr() + 4 * (odl + D), NM, L, xs_e[-1].data_ptr(), xnd.data_ptr(), st_dl.data_ptr(), Me, D)
+            self.marks['enc_fwd_end'] = len(f.calls)  # (it is encoder work: the mark moves behind it)
+        else:
+            f.add('mdt_ln_modulate_fwd', xs_e[-1].data_ptr(), mod.data_ptr() + 4 * odl, mod.data_ptr() + 4 * (odl + D), NM, L,
+                  xnd.data_ptr(), st_dl.data_ptr(), Me, D)
         f.add('mdt_gemm_nt', C.byref(self._k(_nt(xnd.data_ptr(), D, Wp('model.decoder_layer.linear.weight'), D, Me, Dd, D,
                                                bias=Pf('model.decoder_layer.linear.bias'), epi=EPI_BF16, out=xdec.data_ptr(), ldo=Dd))))
         Md = B * T
@@ -578,8 +591,11 @@ class PassPlan:
         f.add('mdt_unmask_fwd', xdec.data_ptr(), (ids32.data_ptr() + 4 * T) if self.masked else None, 2 * T,
               Pf('model.mask_token') if use_mt else None, eng.dpos.data_ptr(), xd0.data_ptr(), B, T, self.lv_arg, Dd, L)
         xs_d = [xd0]
-        for i in range(sp.ddepth):
-            xs_d.append(self._block_fwd(f'model.decoder_blocks.{i}', 'd', i, xs_d[-1], mod, sp.mod_off('dec', i), Dd, sp.dheads, T, Md))
+        pend = None
+        for i in range(sp.ddepth):  # (the last block forms its own output: mdt_final_fwd reads it)
+            xo, pend = self._block_fwd(f'model.decoder_blocks.{i}', 'd', i, xs_d[-1], mod, sp.mod_off('dec', i), Dd, sp.dheads, T, Md,
+                                       pending=pend, defer_out=fuse and i + 1 < sp.ddepth)
+            xs_d.append(xo)
         ofin = sp.mod_off('fin')
         st_f = self.f32('st_f', Md, 2)
         f.add('mdt_final_fwd', xs_d[-1].data_ptr(), mod.data_ptr() + 4 * ofin, mod.data_ptr() + 4 * (ofin + Dd), NM,
@@ -803,8 +819,10 @@ class PassPlan:
         self.bwd.add_callback(cb)
 
     # ---- one DiT block ---------------------------------------------------------------------
-    def _block_fwd(self, prefix, tag, i, x_in, mod, moff, W, heads, rows, M, lvalid=0):
-        """DiTBlock.forward (models/maskdit.py:188-192) as 7 launches."""
+    def _block_fwd(self, prefix, tag, i, x_in, mod, moff, W, heads, rows, M, lvalid=0, pending=None, defer_out=False):
+        """DiTBlock.forward (models/maskdit.py:188-192) as 7 launches.  `pending` = (xres, y, gate) of the previous block's
+        MLP branch: this block's first LayerNorm pass then forms x_in = xres + gate * y itself (FUSE_RES_LN); `defer_out`
+        hands this block's own MLP residual to whoever normalises its output next.  Returns (x_out buffer, pending)."""
         eng, lay, f = self.eng, self.eng.lay, self.fwd
         NM = eng.sp.n_mod
         hd = W // heads
@@ -827,23 +845,38 @@ class PassPlan:
             xout = self.f32(f'x_{tag}{i + 1}', M, W)
         else:  # ping-pong
             xout = self.f32(f'x_{tag}pp{(i + 1) % 2}', M, W)
-        f.add('mdt_ln_modulate_fwd', x_in.data_ptr(), sh1, sc1, NM, rows, xn1.data_ptr(), st1.data_ptr(), M, W)
+        tr = self.train
+        fuse = tr and FUSE_RES_LN
+        if pending is not None:  # x_in = xres + gate * y (the previous block's MLP residual) is formed by this pass
+            f.add('mdt_ln_modulate_fwd_res', pending[0].data_ptr(), pending[1].data_ptr(), pending[2], NM, sh1, sc1, NM, rows,
+                  x_in.data_ptr(), xn1.data_ptr(), st1.data_ptr(), M, W)
+        else:
+            f.add('mdt_ln_modulate_fwd', x_in.data_ptr(), sh1, sc1, NM, rows, xn1.data_ptr(), st1.data_ptr(), M, W)
         f.add('mdt_gemm_nt', C.byref(self._k(_nt(xn1.data_ptr(), W, Wp('attn.qkv.weight'), W, M, 3 * W, W, bias=Pf('attn.qkv.bias'),
                                                epi=EPI_BF16, out=qkv.data_ptr(), ldo=3 * W))))
         f.add('mdt_attn_fwd', qkv.data_ptr(), ao.data_ptr(), lse.data_ptr(), B, rows, heads, hd, lvalid)
         # the bf16 copies of the branch outputs (ya, ym) and the pre-activation h are saved for the
         # backward only: inference plans skip those stores (2 of 10 resp. 2 of 4 epilogue bytes / element)
-        tr = self.train
-        f.add('mdt_gemm_nt', C.byref(self._k(_nt(ao.data_ptr(), W, Wp('attn.proj.weight'), W, M, W, W, bias=Pf('attn.proj.bias'),
-                                               epi=EPI_GATE_RES, out=ya.data_ptr() if tr else 0, ldo=W, outf=xmid.data_ptr(), ldof=W,
-                                               res=x_in.data_ptr(), ldres=W, gate=g1, gate_ld=NM, rps=rows))))
-        f.add('mdt_ln_modulate_fwd', xmid.data_ptr(), sh2, sc2, NM, rows, xn2.data_ptr(), st2.data_ptr(), M, W)
+        if fuse:  # the GEMM stores y only; x_mid = x_in + g1 * y is formed by the LayerNorm pass that consumes it
+            f.add('mdt_gemm_nt', C.byref(self._k(_nt(ao.data_ptr(), W, Wp('attn.proj.weight'), W, M, W, W, bias=Pf('attn.proj.bias'),
+                                                   epi=EPI_BF16, out=ya.data_ptr(), ldo=W))))
+            f.add('mdt_ln_modulate_fwd_res', x_in.data_ptr(), ya.data_ptr(), g1, NM, sh2, sc2, NM, rows, xmid.data_ptr(),
+                  xn2.data_ptr(), st2.data_ptr(), M, W)
+        else:
+            f.add('mdt_gemm_nt', C.byref(self._k(_nt(ao.data_ptr(), W, Wp('attn.proj.weight'), W, M, W, W, bias=Pf('attn.proj.bias'),
+                                                   epi=EPI_GATE_RES, out=ya.data_ptr() if tr else 0, ldo=W, outf=xmid.data_ptr(), ldof=W,
+                                                   res=x_in.data_ptr(), ldres=W, gate=g1, gate_ld=NM, rps=rows))))
+            f.add('mdt_ln_modulate_fwd', xmid.data_ptr(), sh2, sc2, NM, rows, xn2.data_ptr(), st2.data_ptr(), M, W)
         f.add('mdt_gemm_nt', C.byref(self._k(_nt(xn2.data_ptr(), W, Wp('mlp.fc1.weight'), W, M, 4 * W, W, bias=Pf('mlp.fc1.bias'),
                                                epi=EPI_GELU, out=h.data_ptr() if tr else 0, ldo=4 * W, out2=a.data_ptr(), ldo2=4 * W))))
+        if fuse and defer_out:
+            f.add('mdt_gemm_nt', C.byref(self._k(_nt(a.data_ptr(), 4 * W, Wp('mlp.fc2.weight'), 4 * W, M, W, 4 * W, bias=Pf('mlp.fc2.bias'),
+                                                   epi=EPI_BF16, out=ym.data_ptr(), ldo=W))))
+            return xout, (xmid, ym, g2)
         f.add('mdt_gemm_nt', C.byref(self._k(_nt(a.data_ptr(), 4 * W, Wp('mlp.fc2.weight'), 4 * W, M, W, 4 * W, bias=Pf('mlp.fc2.bias'),
                                                epi=EPI_GATE_RES, out=ym.data_ptr() if tr else 0, ldo=W, outf=xout.data_ptr(), ldof=W,
                                                res=xmid.data_ptr(), ldres=W, gate=g2, gate_ld=NM, rps=rows))))
-        return xout
+        return xout, None
 
     def _gate_info(self, prefix, tag, i, mod, dmod, moff, W, Gf):
         """Trailing arguments of mdt_ln_modulate_bwd_gate for the MLP residual gate of block (tag, i):

@@ -90,6 +90,17 @@ def ln_modulate_fwd(x, shift, scale, mod_ld, rows_per_sample):
     return xn, stats
 
 
+def ln_modulate_fwd_res(xres, y, gate, gate_ld, shift, scale, mod_ld, rows_per_sample):
+    """x = xres + gate[b] * y; (xn, stats) = ln_modulate_fwd(x) in one pass (mdt_ln_modulate_fwd_res)."""
+    M, D = xres.shape
+    x = torch.empty(M, D, device=xres.device, dtype=torch.float32)
+    xn = torch.empty(M, D, device=xres.device, dtype=torch.bfloat16)
+    stats = torch.empty(M, 2, device=xres.device, dtype=torch.float32)
+    call('mdt_ln_modulate_fwd_res', p(xres), p(y), p(gate), gate_ld, p(shift), p(scale), mod_ld, rows_per_sample, p(x), p(xn), p(stats),
+         M, D, stream_ptr())
+    return x, xn, stats
+
+
 def ln_modulate_bwd(dxn, x, stats, scale, mod_ld, rows_per_sample, dx, accumulate, dshift, dscale, dmod_ld):
     M, D = x.shape
     call('mdt_ln_modulate_bwd', p(dxn), p(x), p(stats), p(scale), mod_ld, rows_per_sample, p(dx), int(accumulate),

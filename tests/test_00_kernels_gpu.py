@@ -633,6 +633,27 @@ def test_ln_modulate_fwd_bwd(B_, L, D):
     close(dx2, x.grad, 1e-4, 'ln_mod dx (overwrite)')
 
 
+@pytest.mark.parametrize('B_,L,D', [(3, 128, 1152), (2, 256, 512), (5, 64, 384), (2, 64, 1280)])
+def test_ln_modulate_fwd_res_is_gate_res_then_ln_bit_for_bit(B_, L, D):
+    """mdt_ln_modulate_fwd_res (round 6: the residual add formed by the LayerNorm pass that consumes it) against the path of
+    rounds 1-5 -- MDT_EPI_GATE_RES epilogue of the GEMM, then mdt_ln_modulate_fwd -- on the same GEMM: x, xn and the
+    statistics must be BIT-identical (y is the bf16 value both forms add)."""
+    torch.manual_seed(12)
+    M, K = B_ * L, 256
+    A = bf(torch.randn(M, K, device=DEV) * 0.5)
+    W = bf(torch.randn(D, K, device=DEV) * 0.06)
+    bias = torch.randn(D, device=DEV) * 0.1
+    res = torch.randn(M, D, device=DEV)
+    mod = torch.randn(B_, 3 * D, device=DEV) * 0.5   # gate | shift | scale
+    y_old, _, x_old = ops.gemm_nt(A, W, bias=bias, epi=ops.EPI_GATE_RES, res=res, gate=mod[:, :D], gate_ld=3 * D, rows_per_sample=L)
+    xn_old, st_old = ops.ln_modulate_fwd(x_old, mod[:, D:2 * D], mod[:, 2 * D:], 3 * D, L)
+    y_new, _, _ = ops.gemm_nt(A, W, bias=bias, epi=ops.EPI_BF16)
+    assert torch.equal(y_new.view(torch.int16), y_old.view(torch.int16))
+    x_new, xn_new, st_new = ops.ln_modulate_fwd_res(res, y_new, mod[:, :D], 3 * D, mod[:, D:2 * D], mod[:, 2 * D:], 3 * D, L)
+    assert torch.equal(x_new.view(torch.int32), x_old.view(torch.int32)), 'x = xres + gate * y differs from the GATE_RES epilogue'
+    assert torch.equal(xn_new.view(torch.int16), xn_old.view(torch.int16)) and torch.equal(st_new, st_old)
+
+
 @pytest.mark.parametrize('L,Lv,hd', [(192, 179, 64), (128, 100, 72), (256, 179, 32), (128, 65, 64), (256, 193, 72), (512, 449, 72), (1024, 897, 32)])
 def test_attention_padded_keys(L, Lv, hd):
     """L_valid < L: rows >= L_valid are padding -- zero probability as keys; with dout = 0 on them the
