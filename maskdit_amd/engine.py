@@ -58,6 +58,7 @@ FUSE_COLSUM = os.environ.get('MDT_FUSE_COLSUM', '1') != '0'  # fc1 bias gradient
 # their bf16 output (plain class) -- 14 instead of 16 B per element, bit-identical x.  MDT_FUSE_RES_LN=0: the MDT_EPI_GATE_RES
 # epilogues of rounds 1-5 (A/B runs).  Inference plans keep GATE_RES: they do not store the branch output at all.
 FUSE_RES_LN = os.environ.get('MDT_FUSE_RES_LN', '1') != '0'
+FUSE_RES_LN_EVAL = os.environ.get('MDT_FUSE_RES_LN_EVAL', '0') != '0'  # the same in inference plans (A/B)
 
 
 def _rup(x, m):
@@ -564,7 +565,7 @@ class PassPlan:
               Pf('model.x_embedder.proj.bias'), eng.pos.data_ptr(), ids32.data_ptr() if ids32 is not None else None,
               2 * T, x0.data_ptr(), B, sp.C, sp.R, sp.patch, L, D)
         xs_e = [x0]
-        fuse = train and FUSE_RES_LN
+        fuse = FUSE_RES_LN and (train or FUSE_RES_LN_EVAL)
         pend = None  # (xres, y, gate address): the residual add the NEXT LayerNorm pass has to perform into xs_e[-1]
         for i in range(sp.depth):
             xo, pend = self._block_fwd(f'model.blocks.{i}', 'e', i, xs_e[-1], mod, sp.mod_off('enc', i), D, sp.heads, L, Me,
@@ -846,7 +847,7 @@ class PassPlan:
         else:  # ping-pong
             xout = self.f32(f'x_{tag}pp{(i + 1) % 2}', M, W)
         tr = self.train
-        fuse = tr and FUSE_RES_LN
+        fuse = FUSE_RES_LN and (tr or FUSE_RES_LN_EVAL)
         if pending is not None:  # x_in = xres + gate * y (the previous block's MLP residual) is formed by this pass
             f.add('mdt_ln_modulate_fwd_res', pending[0].data_ptr(), pending[1].data_ptr(), pending[2], NM, sh1, sc1, NM, rows,
                   x_in.data_ptr(), xn1.data_ptr(), st1.data_ptr(), M, W)
