@@ -287,6 +287,7 @@ class EDMPrecond(nn.Module):
                 p.copy_(src[name])
                 p.requires_grad_(src[name].requires_grad)
         new.train(self.training)
+        new.eval_precision = self.eval_precision
         memo[id(self)] = new
         return new
 

@@ -56,6 +56,12 @@ def test_module_surface_cpu():
         M.Losses['edm']()(net, torch.zeros(1, 4, 32, 32), torch.zeros(1, 1000))
     with pytest.raises(NotImplementedError):
         M.Precond_models['edm'](img_resolution=32, img_channels=4, num_classes=1000, model_type='DiT-S/2', pad_cls_token=True)
+    # inference precision switch (round 6): default bf16, validated, and it is a host-side attribute (no GPU needed to set it)
+    assert net.eval_precision == 'bf16' and net.set_eval_precision('fp32') is net and net.eval_precision == 'fp32'
+    with pytest.raises(ValueError):
+        net.set_eval_precision('tf32')
+    with pytest.raises(M.MaskDiTLibError):   # ... and the fp32 path fails as loudly off-GPU as the bf16 one
+        net(torch.zeros(1, 4, 32, 32), torch.ones(1))
 
 
 def test_schedules_and_config():
