@@ -56,6 +56,66 @@ __device__ __forceinline__ float gelu_tanh_f32(float x) {
 }
 __device__ __forceinline__ float silu_f32(float x) { return x / (1.f + expf(-x)); }
 
+// ---- epilogue shared by the GEMM forms: the lane's output row m = block row lane & 31; register quad q4 of block jj =
+// columns nq .. nq + 3 (the accumulator blocks are the TRANSPOSED output blocks: see fmma)
+template <int MB, int NB>
+__device__ __forceinline__ void f32_epilogue(const Params& p, f32x16 (&acc)[MB][NB], int m0, int n0, int wm, int wn, int r, int kh,
+                                             float* __restrict__ out) {
+  const int epi = p.epi;
+  const bool vec = p.vec_ok;  // 16-byte accesses legal (pitches / bases multiples of 4 floats; checked by the host entry)
+#pragma unroll
+  for (int i = 0; i < MB; ++i) {
+    const int m = m0 + (wm * MB + i) * 32 + r;
+    if (m >= p.M) continue;
+    float* orow = out + (long)m * p.ldo;
+    const float* rrow = epi == MDT_F32EPI_GATE_RES ? p.res + (long)m * p.ldres : nullptr;
+    const float* grow = (epi == MDT_F32EPI_GATE_RES && p.gate) ? p.gate + (long)(m / p.rps) * p.gate_ld : nullptr;
+#pragma unroll
+    for (int jj = 0; jj < NB; ++jj) {
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const int nq = n0 + (wn * NB + jj) * 32 + 8 * q4 + 4 * kh;
+        if (nq >= p.N) continue;
+        float y[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = acc[i][jj][4 * q4 + e];
+        if (vec && nq + 4 <= p.N) {
+          if (p.bias) {
+            const f32x4 b4 = *(const f32x4*)(p.bias + nq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] += b4[e];
+          }
+          if (epi == MDT_F32EPI_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = gelu_tanh_f32(y[e]);
+          } else if (epi == MDT_F32EPI_SILU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = silu_f32(y[e]);
+          } else if (epi == MDT_F32EPI_GATE_RES) {
+            const f32x4 r4 = *(const f32x4*)(rrow + nq);
+            f32x4 g4 = (f32x4){1.f, 1.f, 1.f, 1.f};
+            if (grow) g4 = *(const f32x4*)(grow + nq);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = r4[e] + g4[e] * y[e];
+          }
+          *(f32x4*)(orow + nq) = (f32x4){y[0], y[1], y[2], y[3]};
+        } else {  // ragged / unaligned: element by element
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int n = nq + e;
+            if (n >= p.N) continue;
+            float v = y[e] + (p.bias ? p.bias[n] : 0.f);
+            if (epi == MDT_F32EPI_GELU) v = gelu_tanh_f32(v);
+            else if (epi == MDT_F32EPI_SILU) v = silu_f32(v);
+            else if (epi == MDT_F32EPI_GATE_RES) v = rrow[n] + (grow ? grow[n] : 1.f) * v;
+            orow[n] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
 // BKT = floats per K-tile (32 or 16): 128-byte or 64-byte LDS rows of BKT / 4 16-byte chunks, chunk c of row r stored at
 // chunk c ^ (r & (BKT / 4 - 1)).
 template <int WM, int WN, int MB, int NB, int BKT, bool BKM>
@@ -253,60 +313,142 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(const Params p, const 
     if (kt + 1 < nk) step(std::integral_constant<int, 1>{}, kt + 1);
   }
 
-  // ---- epilogue: the lane's output row m = block row lane & 31; register quad q4 of block jj = columns nq .. nq + 3
-  const int epi = p.epi;
-  const bool vec = p.vec_ok;  // 16-byte accesses legal (pitches / bases multiples of 4 floats; checked by the host entry)
-#pragma unroll
-  for (int i = 0; i < MB; ++i) {
-    const int m = m0 + (wm * MB + i) * 32 + r;
-    if (m >= p.M) continue;
-    float* orow = out + (long)m * p.ldo;
-    const float* rrow = epi == MDT_F32EPI_GATE_RES ? p.res + (long)m * p.ldres : nullptr;
-    const float* grow = (epi == MDT_F32EPI_GATE_RES && p.gate) ? p.gate + (long)(m / p.rps) * p.gate_ld : nullptr;
-#pragma unroll
-    for (int jj = 0; jj < NB; ++jj) {
-#pragma unroll
-      for (int q4 = 0; q4 < 4; ++q4) {
-        const int nq = n0 + (wn * NB + jj) * 32 + 8 * q4 + 4 * kh;
-        if (nq >= p.N) continue;
-        float y[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = acc[i][jj][4 * q4 + e];
-        if (vec && nq + 4 <= p.N) {
-          if (p.bias) {
-            const f32x4 b4 = *(const f32x4*)(p.bias + nq);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] += b4[e];
-          }
-          if (epi == MDT_F32EPI_GELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = gelu_tanh_f32(y[e]);
-          } else if (epi == MDT_F32EPI_SILU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = silu_f32(y[e]);
-          } else if (epi == MDT_F32EPI_GATE_RES) {
-            const f32x4 r4 = *(const f32x4*)(rrow + nq);
-            f32x4 g4 = (f32x4){1.f, 1.f, 1.f, 1.f};
-            if (grow) g4 = *(const f32x4*)(grow + nq);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) y[e] = r4[e] + g4[e] * y[e];
-          }
-          *(f32x4*)(orow + nq) = (f32x4){y[0], y[1], y[2], y[3]};
-        } else {  // ragged / unaligned: element by element
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int n = nq + e;
-            if (n >= p.N) continue;
-            float v = y[e] + (p.bias ? p.bias[n] : 0.f);
-            if (epi == MDT_F32EPI_GELU) v = gelu_tanh_f32(v);
-            else if (epi == MDT_F32EPI_SILU) v = silu_f32(v);
-            else if (epi == MDT_F32EPI_GATE_RES) v = rrow[n] + (grow ? grow[n] : 1.f) * v;
-            orow[n] = v;
-          }
-        }
-      }
-    }
+  f32_epilogue<MB, NB>(p, acc, m0, n0, wm, wn, r, kh, out);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The same GEMM with its operand tiles moved by LDS-DMA (global_load_lds, 16 B per lane: 1 KiB of LDS per wave-instruction,
+// no staging registers, no ds_write, no per-chunk selects) -- for the Linear layers: 128 x 128 x 32 tile, B = [N][K], K a
+// multiple of 32.  The K loop of the register-staged form costs the MFMA waves 8 global loads + 8 LDS stores + ~60 VALU per
+// K-tile (15 % of the launch by the ablation of profiles/r6_f32_pmc.txt); here it is 8 DMA instructions.  hipcc's waitcnt pass
+// does not know which LDS bytes a DMA in flight writes and would drain vmcnt(0) in front of every LDS read it sees, so the
+// fragment reads are inline asm with hand-placed lgkmcnt waits (the idiom of gemm_tn8.hip): reads retire in order, so
+// "all but the newest MB + NB reads have landed" is exactly "the previous fragment set is complete".
+// Schedule of K-tile kt (buffer b = kt & 1): [DMA of tile kt + 1 into b ^ 1][reads g1][MFMA g0][reads g2][MFMA g1][reads g3]
+// [MFMA g2][vmcnt(0) + barrier][reads g0 of tile kt + 1][MFMA g3].  b ^ 1 held tile kt - 1, whose last reads were waited for
+// before barrier(kt - 1); the DMA has the whole K-tile to land.  Rows beyond M / N are clamped to the last row: they
+// only feed output rows / columns the epilogue never stores.
+template <int N> __device__ __forceinline__ void f32_wait_lgkm() {
+  __builtin_amdgcn_s_waitcnt(15 | (7 << 4) | ((N & 15) << 8) | (3 << 14));  // vmcnt / expcnt unconstrained
+}
+__device__ __forceinline__ f32x4 f32_lds_read16(unsigned addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+
+template <int MB, int NB, int BKT, int MINW>
+__global__ __launch_bounds__(256, MINW) void gemm_f32_dma_kernel(const Params p, const int tiles_m, const int tiles_n) {
+  constexpr int WN = 2, BM = 2 * MB * 32, BN = 2 * NB * 32, NG = BKT / 8;
+  constexpr int CPRW = BKT / 4, RP = 64 / CPRW;          // 16-byte chunks per LDS row; rows per 1 KiB piece
+  constexpr int A_PC = BM / RP / 4, B_PC = BN / RP / 4;  // pieces per wave and K-tile
+  static_assert(BKT == 32 || BKT == 16, "K-tile depth");
+  static_assert(A_PC >= 1 && B_PC >= 1 && NG >= 2, "tile too small");
+  __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * BKT];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int nt = tiles_m * tiles_n;
+  int t = blockIdx.x;
+  {
+    const int q = nt >> 3, r = nt & 7, x = t & 7, i = t >> 3;
+    t = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
   }
+  constexpr int GM = 8;
+  const int per_group = GM * tiles_n, grp = t / per_group, first_m = grp * GM;
+  const int gm = min(tiles_m - first_m, GM), in_g = t - grp * per_group;
+  const int tm = first_m + in_g % gm, tn = in_g / gm;
+  const int m0 = tm * BM, n0 = tn * BN;
+  float* __restrict__ out = p.out;
+
+  f32x16 acc[MB][NB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // DMA sources: piece pc = wave + 4 i covers tile rows RP pc .. RP pc + RP - 1; lane l brings row RP pc + l / CPRW, global
+  // chunk (l % CPRW) ^ (row & (CPRW - 1)) -- the XOR swizzle of the register-staged form, applied through the source address
+  const int lrow = lane / CPRW, lchunk = (lane % CPRW) ^ (lrow & (CPRW - 1));
+  const float* pa[A_PC];
+  const float* pb[B_PC];
+#pragma unroll
+  for (int i = 0; i < A_PC; ++i) pa[i] = p.A + (long)min(m0 + RP * (wave + 4 * i) + lrow, p.M - 1) * p.lda + 4 * lchunk;
+#pragma unroll
+  for (int i = 0; i < B_PC; ++i) pb[i] = p.B + (long)min(n0 + RP * (wave + 4 * i) + lrow, p.N - 1) * p.ldb + 4 * lchunk;
+  auto dma = [&](int buf, int k0) {
+    float* la = lds[buf] + wave * 256;          // 1 KiB = 256 floats per piece
+    float* lb = lds[buf] + BM * BKT + wave * 256;
+#pragma unroll
+    for (int i = 0; i < A_PC; ++i) glds16(pa[i] + k0, la + i * 1024);
+#pragma unroll
+    for (int i = 0; i < B_PC; ++i) glds16(pb[i] + k0, lb + i * 1024);
+  };
+
+  const int nk = p.K / BKT;
+  const int r = lane & 31, kh = lane >> 5;
+  const unsigned lds0 = (unsigned)(size_t)LDS_PTR(&lds[0][0]);
+  constexpr unsigned BUF_BYTES = (BM + BN) * BKT * 4;
+  unsigned ra[MB], rb[NB];  // byte offsets of this lane's rows inside a buffer
+#pragma unroll
+  for (int i = 0; i < MB; ++i) ra[i] = (unsigned)(((wm * MB + i) * 32 + r) * BKT) * 4u;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) rb[i] = (unsigned)((BM + (wn * NB + i) * 32 + r) * BKT) * 4u;
+  const int rsw = r & (CPRW - 1);
+  f32x4 fa[2][MB], fb[2][NB];
+  auto fload = [&](int set, int buf, int j) {
+    const unsigned cb = lds0 + buf * BUF_BYTES + 16u * ((2 * j + kh) ^ rsw);
+#pragma unroll
+    for (int i = 0; i < MB; ++i) fa[set][i] = f32_lds_read16(cb + ra[i]);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) fb[set][i] = f32_lds_read16(cb + rb[i]);
+  };
+  auto fmma = [&](int set) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int jj = 0; jj < NB; ++jj)
+          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[set][jj][e], fa[set][i][e], acc[i][jj], 0, 0, 0);
+  };
+#define F32_FENCE() __builtin_amdgcn_sched_barrier(0)
+  dma(0, 0);
+  __syncthreads();  // (hipcc waits vmcnt(0) for the release: tile 0 has landed)
+  F32_FENCE();
+  fload(0, 0, 0);
+  F32_FENCE();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const bool more = kt + 1 < nk;
+    if (more) {  // every read of the OTHER buffer (tile kt - 1) was waited for before barrier(kt - 1): refill it right away --
+      dma(buf ^ 1, (kt + 1) * BKT);  // the DMA then has this whole K-tile of MFMAs to land (issued behind g2: 7 % slower)
+      F32_FENCE();
+    }
+#pragma unroll
+    for (int g = 0; g + 1 < NG; ++g) {
+      fload((g + 1) & 1, buf, g + 1);
+      F32_FENCE();
+      f32_wait_lgkm<MB + NB>();  // the set about to be used has landed; the one just requested may be in flight
+      F32_FENCE();
+      fmma(g & 1);
+      F32_FENCE();
+    }
+    f32_wait_lgkm<0>();  // this wave's reads of `buf` are complete before anyone may overwrite it (after the next barrier)
+    F32_FENCE();
+    __syncthreads();     // + vmcnt(0): tile kt + 1 is in LDS for every wave
+    F32_FENCE();
+    if (more) fload(NG & 1, buf ^ 1, 0);
+    F32_FENCE();
+    fmma((NG - 1) & 1);
+    F32_FENCE();
+    if (more) f32_wait_lgkm<0>();  // (set 0 of the next tile; the next iteration's first wait counts from a clean queue)
+    F32_FENCE();
+  }
+#undef F32_FENCE
+  f32_epilogue<MB, NB>(p, acc, m0, n0, wm, wn, r, kh, out);
 }
 
 template <int WM, int WN, int MB, int NB, int BKT>
@@ -607,6 +749,19 @@ extern "C" int mdt_gemm_f32(const mdt_gemm_f32_args* a, mdt_stream_t stream) {
   // column tile: 128 unless the problem is narrower (attention's p v with N = head_dim).  (A 256 x 128 tile with 16-deep
   // K-tiles -- 23 instead of 31 operand bytes per kFLOP -- measured the same 0.65-0.71 of peak as this one,
   // profiles/r6_f32_bench_tiles.txt, and does not fit 256 registers with the two-ahead load staging: not instantiated.)
+  // the LDS-DMA form for the Linear layers (MDT_F32_DMA=0: the register-staged form, A/B runs)
+  static int dma_knob = -1;
+  if (dma_knob < 0) {
+    const char* e = getenv("MDT_F32_DMA");
+    dma_knob = e ? atoi(e) : 1;
+  }
+  if (dma_knob && a->N > 64 && !bkm && batch == 1 && a->K % 32 == 0 && a->K >= 64 && a->M >= 128) {
+    // (measured and not instantiated, profiles/r6_f32_dma_ab.txt: 256 x 128 x 16 tiles 4 % slower, 128 x 128 x 16 with up to
+    // four workgroups per CU 11 % slower than this 128 x 128 x 32 form with two)
+    const int tm = cdiv(p.M, 128), tn = cdiv(p.N, 128);
+    hipLaunchKernelGGL((f32p::gemm_f32_dma_kernel<2, 2, 32, 2>), dim3(tm * tn), dim3(256), 0, st, p, tm, tn);
+    return mdt_check_launch("gemm_f32 (LDS-DMA)");
+  }
   if (a->N > 64) return f32p::launch<2, 2, 2, 2, 32>(p, bkm, batch, st);
   if (a->N > 32) return f32p::launch<4, 1, 1, 2, 32>(p, bkm, batch, st);
   return f32p::launch<4, 1, 1, 1, 32>(p, bkm, batch, st);

@@ -1090,6 +1090,41 @@ def test_gemm_f32_vs_fp64(M, N, K, epi):
         _f32_close(out2, ref, 2e-6, f'gemm_f32 k-major {M}x{N}x{K}')
 
 
+@pytest.mark.parametrize('M,N,K,epi', [(4096, 1152, 1152, 'GATE_RES'), (2048, 4608, 1152, 'GELU'), (1000, 384, 1536, 'NONE'), (256, 128, 64, 'NONE')])
+def test_gemm_f32_dma_poisoned_lds_stress(M, N, K, epi):
+    """The LDS-DMA form of mdt_gemm_f32 (gemm_f32_dma_kernel: operand tiles by global_load_lds, fragment reads in inline asm
+    behind hand-placed lgkmcnt waits, the DMA of K-tile kt + 1 issued at the top of K-tile kt into the buffer tile kt - 1 was
+    read from).  Every launch runs behind mdt_lds_poison (a fragment read before its DMA landed, or a refill before the last
+    read of the old tile, would surface as NaN / a wrong sum), operands alternately cache-warm and evicted; all launches must
+    be BIT-identical to the first, and that one within fp32 rounding of fp64.  Ragged M (1000) exercises the clamped rows."""
+    torch.manual_seed(21)
+    A = torch.randn(M, K, device=DEV)
+    W = torch.randn(N, K, device=DEV) * K ** -0.5
+    b = torch.randn(N, device=DEV)
+    kw = dict(bias=b, epi=getattr(ops, 'F32EPI_' + epi))
+    ref = A.double() @ W.double().t() + b.double()
+    if epi == 'GELU':
+        ref = F.gelu(ref, approximate='tanh')
+    elif epi == 'GATE_RES':
+        res = torch.randn(M, N, device=DEV)
+        gate = torch.randn(M // 256, N, device=DEV)
+        kw.update(res=res, gate=gate, gate_ld=N, rows_per_sample=256)
+        ref = res.double() + gate.double().repeat_interleave(256, 0) * ref
+    flush = torch.empty(1 << 26, device=DEV, dtype=torch.float32)
+    first = None
+    for rep in range(40):
+        if rep & 1:
+            flush.fill_(float(rep))
+        _poison_lds()
+        out = torch.full((M, N), float('nan'), device=DEV)
+        ops.gemm_f32(A, W, out, M, N, K, **kw)
+        if first is None:
+            first = out
+            _f32_close(out, ref, 2e-6, f'gemm_f32 (LDS-DMA) {M}x{N}x{K} {epi}')
+        else:
+            assert torch.equal(out.view(torch.int32), first.view(torch.int32)), f'launch {rep} differs from launch 0'
+
+
 @pytest.mark.parametrize('B_,L,H,hd', [(3, 256, 16, 72), (2, 256, 16, 32), (2, 64, 6, 64), (2, 256, 6, 64), (3, 64, 16, 72),
                                        (5, 64, 3, 32), (1, 1024, 2, 32), (2, 128, 3, 80), (1, 512, 2, 72)])
 def test_attention_f32_vs_fp64(B_, L, H, hd):

@@ -69,6 +69,9 @@ WATCH = {
     'gemm_tn8.hip': [(r'gemm_tn8_kernel', 'tn8')],
     'norm.hip': [(r'ln_bwd_gate_split_kernel', 'generic'), (r'ln_modulate_(fwd|bwd)_kernel', 'generic')],
     'gemm.hip': [(r'gemm_(nt|tn)_kernel', 'generic')],
+    # round 6: the fp32 path -- gemm_f32_dma_kernel moves its tiles by LDS-DMA (drained by the vmcnt(0) of __syncthreads) and
+    # reads its fragments with inline-asm ds_read + hand-placed lgkmcnt waits
+    'f32path.hip': [(r'gemm_f32_dma_kernel', 'generic'), (r'gemm_f32_kernel', 'generic'), (r'attn_f32_kernel', 'generic')],
 }
 
 
