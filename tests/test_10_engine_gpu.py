@@ -306,6 +306,25 @@ def test_eval_forward_fp32_at_1024_tokens_vs_oracle():
     assert any(k.startswith('scores_') for k in net.engine().plan(2, False, False, None, 'fp32').buf), 'expected the scores workspace'
 
 
+@pytest.mark.parametrize('model_type', ['DiT-S/2', 'DiT-XL/2'])
+def test_kmajor_weight_shadows_are_exact_transposes(model_type):
+    """mdt_transpose_bf16_batched (the K-major bf16 shadows the data-gradient GEMMs read; round 6: 16-byte fast path): every
+    entry of the engine's transpose table -- the stacked adaLN weight, every qkv / proj / fc1 / fc2 / decoder-layer /
+    t-embedder matrix -- must be the exact transpose of its N-major shadow."""
+    cfg, P, net = _build(model_type, 32, seed=2)
+    eng = net.engine()
+    eng.refresh_shadows()
+    torch.cuda.synchronize()
+    n = 0
+    for src, dst, rows, cols in eng.lay.t_entries:
+        a = eng.W16[src:src + rows * cols].view(rows, cols)
+        b = eng.WT16[dst:dst + rows * cols].view(cols, rows)
+        assert torch.equal(b.view(torch.int16), a.t().contiguous().view(torch.int16)), (src, dst, rows, cols)
+        assert float(a.float().abs().max()) > 0
+        n += 1
+    assert n >= 4 * (cfg['depth'] + 8) + 2
+
+
 def test_generic_net_autograd_path_matches_fused_loss(golden_dir):
     """The reference's own loss arithmetic (train_utils/loss.py:44-52) written in torch on top of
     net(...)['x'] must give the same loss and gradients as the fused EDMLoss."""
