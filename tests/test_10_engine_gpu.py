@@ -306,6 +306,51 @@ def test_eval_forward_fp32_at_1024_tokens_vs_oracle():
     assert any(k.startswith('scores_') for k in net.engine().plan(2, False, False, None, 'fp32').buf), 'expected the scores workspace'
 
 
+@pytest.mark.parametrize('model_type', ['DiT-B/2', 'DiT-L/2', 'DiT-H/2'])
+def test_other_model_sizes_train_and_eval_vs_oracle(model_type):
+    """SURVEY 8a row a21 (the size configs of models/maskdit.py:649-715 at patch 2) END TO END on the GPU, against the CPU
+    oracle on the same seeded inputs: B/2 (D 768, 12 heads of 64), L/2 (D 1024, 16 x 64), H/2 (D 1280, 16 x 80: the head
+    dimension only this size has; 32 blocks) -- masked training loss + every gradient, bf16 and fp32-faithful eval forward
+    (H/2's fp32 attention takes the three-launch form: hd 80 is outside the fused kernel's domain)."""
+    cfg, P, net = _build(model_type, 32, seed=13)
+    B = 4
+    gcpu = torch.Generator().manual_seed(7)
+    images = 0.5 * torch.randn(B, 4, 32, 32, generator=gcpu)
+    labels = torch.zeros(B, 1000)
+    labels[torch.arange(B), torch.randint(0, 1000, (B,), generator=gcpu)] = 1
+    rnd, noise = torch.randn(B, 1, 1, 1, generator=gcpu), torch.randn(B, 4, 32, 32, generator=gcpu)
+    mnoise = torch.rand(B, 256, generator=gcpu)
+    md = M.get_mask(B, 256, 0.5, DEV, noise=mnoise.to(DEV))
+    net.zero_grad(set_to_none=True)
+    loss = M.Losses['edm']().with_draws(net, images.to(DEV), labels.to(DEV), rnd.to(DEV), noise.to(DEV), md, mae_loss_coef=0.1)
+    loss.mean().backward()
+    mdict = {k: torch.from_numpy(v) for k, v in O.get_mask_from_noise(mnoise.numpy(), 0.5).items()}
+    assert torch.equal(md['ids_restore'].cpu(), mdict['ids_restore'])
+    loss_ref, _, grads_ref = O.loss_and_grads(P, cfg, images, labels, rnd, noise, mdict, 0.1)
+    rl = ((loss.detach().cpu() - loss_ref).abs() / loss_ref.abs()).max().item()
+    assert rl <= TOL_LOSS, f'{model_type}: loss rel err {rl:.3e}'
+    params = dict(net.named_parameters())
+    worst = ('', 0.0)
+    for k, gr in grads_ref.items():
+        got = params[k].grad
+        assert got is not None, k
+        num = (got.detach().cpu().double() - gr.double()).norm().item()
+        den = gr.double().norm().item()
+        if num / (den + 1e-12) > worst[1]:
+            worst = (k, num / (den + 1e-12))
+        assert num <= TOL_GRAD * den + 1e-7, f'{model_type} {k}: grad rel L2 err {num / (den + 1e-12):.3e}'
+    net.eval()
+    x = torch.randn(2, 4, 32, 32, generator=gcpu) * 2
+    sigma = torch.tensor([0.4, 9.0])
+    with torch.no_grad():
+        ref = O.precond_forward(P, cfg, x, sigma, labels[:2], training=False)
+        eb = _relmax(net(x.to(DEV), sigma.to(DEV), labels[:2].to(DEV))['x'], ref)
+        net.set_eval_precision('fp32')
+        ef = _relmax(net(x.to(DEV), sigma.to(DEV), labels[:2].to(DEV))['x'], ref)
+    print(f'{model_type}: loss rel err {rl:.2e}, worst grad rel L2 {worst[1]:.2e} at {worst[0]}, eval forward bf16 {eb:.2e} / fp32 {ef:.2e}')
+    assert eb <= TOL_D and ef <= TOL_F32
+
+
 @pytest.mark.parametrize('model_type', ['DiT-S/2', 'DiT-XL/2'])
 def test_kmajor_weight_shadows_are_exact_transposes(model_type):
     """mdt_transpose_bf16_batched (the K-major bf16 shadows the data-gradient GEMMs read; round 6: 16-byte fast path): every
