@@ -469,6 +469,7 @@ def main():
                                        'arithmetic': 'exact fp32 (fp32 master weights, fp32 activations, v_mfma_f32_32x32x2_f32)',
                                        'peak_tflops': 157.3,
                                        'model_tflops_per_s': round(sb * evals * 2 * 251.6e9 / t32 / 1e12, 1) if (args.model, R) == ('DiT-XL/2', 32) else None,
+                                       'frac_of_fp32_matrix_peak': round(sb * evals * 2 * 251.6e9 / t32 / 1e12 / 157.3, 4) if (args.model, R) == ('DiT-XL/2', 32) else None,
                                        'bf16_vs_fp32_rel_to_max': round(float((z - z32).abs().max() / z32.abs().max()), 6)}
                     from maskdit_amd import sampler as _smp
                     _smp.release_graphs()
